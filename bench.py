@@ -1,0 +1,232 @@
+#!/usr/bin/env python3
+"""Benchmark of the ptychography hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A *step* is one pass of the hot path over one batch of synthetic scan positions:
+``g = fwd(psi, scan, probe)`` followed by ``adj(g, scan, probe)`` on
+``--nscan`` positions per GPU (BASELINE.json configs[1]: 4096 x (256 x 256)
+complex64, 1 probe mode), plus -- for N > 1 -- the RCCL all-reduce of the object
+update, which is the path's one real exchange step.  Scan positions are sharded
+over ranks (weak scaling: 4096 positions per GPU on a common object).
+
+Rank 0 prints ONE JSON line.  ``value`` is whole-job fwd+adj patterns/s with all
+inputs resident in HBM.  ``roofline`` prices the fwd+adj pair against the HBM
+roofline with the algorithmic bytes of BASELINE.md section 3 and reports live
+per-kernel durations (HIP events on the launch stream, taken inside the library);
+``cpu_baseline`` times the NumPy/SciPy oracle on a bounded sample on this host's
+cores.  Secondary: ``cg_iterations_per_s`` (the reference CG loop on the same
+problem).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "libtike-cufft_amd")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--ndet", type=int, default=256)
+    ap.add_argument("--nprb", type=int, default=256)
+    ap.add_argument("--raster", type=int, default=64, help="raster is RxR positions per GPU")
+    ap.add_argument("--step-px", type=int, default=8)
+    ap.add_argument("--cg-iters", type=int, default=6)
+    ap.add_argument("--chunk", type=int, default=0)
+    ap.add_argument("--cpu-sample", type=int, default=192)
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-cg", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(args, prob):
+    """fwd+adj patterns/s of the oracle (NumPy + scipy.fft on all host cores) on the
+    first ``--cpu-sample`` positions of the same workload."""
+    import scipy.fft
+    from oracle import ptycho_oracle as op
+    cores = len(os.sched_getaffinity(0))
+    ns = min(args.cpu_sample, prob["scan"].shape[1])
+    scan = prob["scan"][:, :ns]
+    done, t_used = 0, 0.0
+    with scipy.fft.set_workers(cores):
+        while t_used < 10.0 and done < 8 * ns:
+            t0 = time.perf_counter()
+            g = op.fwd(prob["psi"], scan, prob["probe"], args.ndet)
+            op.adj(g, scan, prob["probe"], prob["nz"], prob["n"])
+            t_used += time.perf_counter() - t0
+            done += ns
+    return {"value": done / t_used, "unit": "patterns/s", "cores": cores, "kind": "port",
+            "sample": "%d fwd+adj passes over the first %d positions of the workload "
+                      "(oracle/ptycho_oracle.py, complex64, scipy.fft workers=%d), %.1f s"
+                      % (done // ns, ns, cores, t_used)}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    assert world == args.gpus or world == 1, "launch with torch.distributed.run for --gpus > 1"
+    ngpu = world
+
+    import libtike.hipfft as pt
+    from libtike.hipfft import synthetic as syn
+
+    R, step, nprb, ndet = args.raster, args.step_px, args.nprb, args.ndet
+    nscan = R * R
+    # common object covering the raster of all ranks (rank r owns raster rows [rR, (r+1)R))
+    nz, n = syn.object_size_for(R * ngpu, R, step, nprb)
+    rng = np.random.default_rng(1234)
+    psi_h = syn.random_object(nz, n, rng)
+    prb_h = syn.gaussian_probe(nprb)
+    rng_r = np.random.default_rng(1234 + 17 * rank)
+    scan_h = syn.raster_scan(R, R, step, rng_r, y0=float(rank * R * step))
+    prob = {"psi": psi_h, "probe": prb_h, "scan": scan_h, "nz": nz, "n": n}
+
+    dev = torch.device("cuda", local)
+    psi = torch.as_tensor(psi_h, device=dev)
+    prb = torch.as_tensor(prb_h, device=dev)
+    scan = torch.as_tensor(scan_h, device=dev)
+
+    slv = pt.CGPtychoSolver(nscan, nprb, ndet, 1, nz, n,
+                            group=dist.group.WORLD if dist else None)
+    slv.verbose = False
+    if args.chunk:
+        slv.set_chunk(args.chunk)
+
+    def one_step():
+        g = slv.fwd(psi, scan, prb)
+        upd = slv.adj(g, scan, prb)
+        if dist:
+            dist.all_reduce(torch.view_as_real(upd))
+        return upd
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        one_step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if dist:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = 1e3 * elapsed / args.steps
+    value = ngpu * nscan * args.steps / elapsed
+
+    # ---- live per-kernel timing (HIP events inside the library, launch stream) --
+    slv.profile(True)
+    nprof = 3
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record()
+    for _ in range(nprof):
+        g = slv.fwd(psi, scan, prb)
+        slv.adj(g, scan, prb)
+    ev1.record()
+    torch.cuda.synchronize()
+    prof = slv.profile_read()
+    slv.profile(False)
+    pair_ms_events = ev0.elapsed_time(ev1) / nprof
+    kern = {k: {"avg_ms_per_launch": ms / cnt, "launches_per_step": cnt / nprof,
+                "ms_per_step": ms / nprof} for k, (ms, cnt) in prof.items()}
+    kernel_ms = sum(v["ms_per_step"] for v in kern.values())
+    dominant = max(kern, key=lambda k: kern[k]["ms_per_step"])
+    op_bytes = 8.0 * nscan * ndet * ndet + 8.0 * nz * n + 8.0 * nprb * nprb + 8.0 * nscan
+    pair_bytes = 2.0 * op_bytes
+    achieved = pair_bytes / (1e-3 * ms_per_step) / 1e9
+    # the dominant kernel against its own operator's compulsory bytes per launch
+    dom = kern[dominant]
+    dom_bytes = op_bytes / dom["launches_per_step"]
+    roofline = {
+        "bound": "hbm",
+        "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+        "traffic": None,
+        "what": "fwd+adj pair: %.4e algorithmic B per %d-position batch (16*ndet^2 B/pattern "
+                "+ object, probe, scan) / measured ms_per_step" % (pair_bytes, nscan),
+        "dominant_kernel": {
+            "name": dominant, "avg_ms_per_launch": dom["avg_ms_per_launch"],
+            "launches_per_step": dom["launches_per_step"],
+            "algorithmic_bytes_per_launch": dom_bytes,
+            "achieved_GBs": dom_bytes / (1e-3 * dom["avg_ms_per_launch"]) / 1e9,
+            "frac": dom_bytes / (1e-3 * dom["avg_ms_per_launch"]) / 1e9 / HBM_PEAK_GBS,
+        },
+        "kernels": kern,
+        "kernel_ms_per_step": kernel_ms, "pair_ms_hip_events": pair_ms_events,
+    }
+
+    # ---- CG iterations / s (secondary metric of BASELINE.json) -------------------
+    cg = None
+    if not args.no_cg and args.cg_iters > 0:
+        data = (torch.abs(slv.fwd(psi, scan, prb)) ** 2).contiguous()
+        psi0 = torch.ones_like(psi)
+        slv.run(data, psi0, scan.clone(), prb[:, None].clone(), piter=2)     # warm-up
+        fence()
+        t0 = time.perf_counter()
+        slv.run(data, psi0, scan.clone(), prb[:, None].clone(), piter=args.cg_iters)
+        fence()
+        dt = time.perf_counter() - t0
+        if dist:
+            t = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        cg = {"cg_iterations_per_s": args.cg_iters / dt, "cg_iters_timed": args.cg_iters,
+              "cg_config": "gaussian, 1 mode, no probe recovery, position correction on (reference loop)"}
+        del data
+
+    out = {
+        "metric": "fwd+adj patterns/s",
+        "value": value, "unit": "patterns/s",
+        "n_gpus": ngpu, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "complex64 (f32)", "data": "synthetic",
+        "config": {"workload": "%d scan positions/GPU x (%dx%d) detector, complex64, nprb=%d, "
+                               "1 probe mode, object %dx%d, raster step %d px + jitter "
+                               "(BASELINE.json configs[1])" % (nscan, ndet, ndet, nprb, nz, n, step),
+                   "nscan_per_gpu": nscan, "ndet": ndet, "nprb": nprb, "object": [nz, n],
+                   "sharding": "scan positions over ranks, object all-reduce (RCCL)" if ngpu > 1 else "single GPU",
+                   "chunk": int(args.chunk)},
+        "roofline": roofline,
+    }
+    if cg:
+        out.update(cg)
+    if rank == 0 and ngpu == 1 and not args.no_cpu:
+        out["cpu_baseline"] = cpu_baseline(args, prob)
+    elif rank == 0:
+        out["cpu_baseline"] = None
+    slv.free()
+    if dist:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

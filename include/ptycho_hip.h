@@ -1,0 +1,93 @@
+/* ptycho_hip.h -- C ABI of libptychohip.so (gfx950 / MI355X).
+ *
+ * Drop-in boundary for the native class `ptychofft` of nikitinvv/libtike-cufft
+ * (reference paths relative to /root/reference):
+ *
+ *   ptychofft::ptychofft(ptheta,nz,n,nscan,ndet,nprb)  src/include/ptychofft.cuh:35-36, src/cuda/ptychofft.cu:5-41
+ *   ptychofft::fwd(g,f,scan,prb)                       src/include/ptychofft.cuh:40,    src/cuda/ptychofft.cu:60-73
+ *   ptychofft::adj(f,g,scan,prb,flg)                   src/include/ptychofft.cuh:42,    src/cuda/ptychofft.cu:76-88
+ *   ptychofft::free() / ~ptychofft()                   src/include/ptychofft.cuh:38,43, src/cuda/ptychofft.cu:44-57
+ *   read-only fields ptheta,nz,n,nscan,ndet,nprb       src/cuda/swig/ptychofft.i:11-16
+ *
+ * Differences from the reference interface, on purpose:
+ *   - plain C functions on an opaque handle instead of a SWIG/pybind11 class;
+ *   - every entry point returns an int status (0 = ok) and validates its
+ *     arguments; ptycho_last_error() describes the last failure of the calling
+ *     thread (the reference returns void and checks nothing);
+ *   - the caller's HIP stream is passed explicitly (the reference uses the
+ *     legacy default stream); no per-call state is kept in the handle;
+ *   - taps outside the object read as zero / are dropped instead of being
+ *     undefined behaviour (the reference only rejects negative positions,
+ *     src/cuda/kernels.cu:39).
+ *
+ * All device pointers are borrowed for the duration of the call.  Layouts
+ * (C-contiguous, complex64 = interleaved float re,im):
+ *   f    object   complex64 [ptheta][nz][n]
+ *   g    farplane complex64 [ptheta][nscan][ndet][ndet]   (DC at [0][0])
+ *   prb  probe    complex64 [ptheta][nprb][nprb]
+ *   scan          float32   [ptheta][nscan][2]  ([..][0] = row/y, [..][1] = column/x)
+ * ndet must be a power of two in [16, 1024]; nprb <= ndet.
+ */
+#ifndef PTYCHO_HIP_H
+#define PTYCHO_HIP_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ptycho_handle_s* ptycho_handle;
+
+enum {
+    PTYCHO_OK = 0,
+    PTYCHO_ERR_ARG = 1,      /* invalid argument / unsupported size */
+    PTYCHO_ERR_HIP = 2,      /* a HIP runtime call failed */
+    PTYCHO_ERR_FREED = 3     /* handle used after ptycho_free */
+};
+
+/* ptychofft ctor: builds the twiddle table and the chunk scratch. */
+int ptycho_create(ptycho_handle* out, size_t ptheta, size_t nz, size_t n,
+                  size_t nscan, size_t ndet, size_t nprb);
+/* ptychofft::free -- idempotent; the handle stays valid for ptycho_get/destroy. */
+int ptycho_free(ptycho_handle h);
+/* ~ptychofft: free + release the handle itself. */
+int ptycho_destroy(ptycho_handle h);
+/* read-only size fields: which = 0 ptheta, 1 nz, 2 n, 3 nscan, 4 ndet, 5 nprb. */
+long long ptycho_get(ptycho_handle h, int which);
+
+/* g = F Q f : probe (x) bilinear patch, 1/ndet, centred zero pad, 2-D DFT. */
+int ptycho_fwd(ptycho_handle h, void* g, const void* f, const void* scan,
+               const void* prb, void* stream);
+/* flg = 0: f   += Q* F* g   (f must be zeroed by the caller, as in the reference)
+ * flg = 1: prb += O* F* g   (prb must be zeroed by the caller)
+ * Same argument order as the reference; g is never modified. */
+int ptycho_adj(ptycho_handle h, void* f, const void* g, const void* scan,
+               void* prb, int flg, void* stream);
+
+/* Batched unnormalised 2-D DFT of nbatch ndet x ndet complex64 tiles
+ * (dir = -1 forward, +1 inverse; dst may equal src).  This is the cuFFT plan of
+ * src/cuda/ptychofft.cu:14-20 exposed for the position registration
+ * (cp.fft.ifft2 in src/libtike/cufft/ptycho.py:204). */
+int ptycho_fft2(ptycho_handle h, void* dst, const void* src, size_t nbatch,
+                int dir, void* stream);
+
+/* Tuning knobs: name = "chunk" (patterns per launch pair, 0 = default). */
+int ptycho_set_option(ptycho_handle h, const char* name, long long value);
+
+/* In-library profiler for bench.py: when enabled, every kernel launch is
+ * bracketed by HIP events on the caller's stream.  ptycho_profile_read waits for
+ * the recorded launches, returns summed milliseconds and launch counts per kernel
+ * (index 0 k_cols<FWD>, 1 k_rows<fwd>, 2 k_rows<inv>, 3 k_cols<ADJ_OBJ>,
+ * 4 k_cols<ADJ_PRB>, 5 k_cols<PLAIN>; n >= 6) and clears the record.
+ * No counterpart in the reference (it has no timing code). */
+int ptycho_profile(ptycho_handle h, int enable);
+int ptycho_profile_read(ptycho_handle h, double* ms, long long* launches, int n);
+
+const char* ptycho_last_error(void);
+const char* ptycho_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,687 @@
+// ptycho_kernels.hip -- gfx950 kernels + C ABI for the ptychography operators.
+//
+// What it replaces in the reference (paths relative to /root/reference):
+//   muloperator flg=2/0/1           src/cuda/kernels.cu:8-108
+//   ptychofft ctor/fwd/adj/free     src/cuda/ptychofft.cu:5-88
+//   cuFFT batched 2-D C2C           src/cuda/ptychofft.cu:14-20,72,85
+//
+// Structure: the 2-D DFT is split into a column pass and a row
+// pass; the probe/object work is fused into the column pass, which owns a strip
+// of C detector columns for a whole group of scan positions and keeps the probe
+// strip (or the probe-gradient accumulators) in registers across positions.
+//
+//   fwd : k_cols<FWD>  gather+bilerp+probe -> DFT over y -> strip of g
+//         k_rows       in-place DFT over x on g (zero columns are never read)
+//   adj : k_rows       inverse DFT over x, g -> chunk scratch (g untouched)
+//         k_cols<ADJ>  inverse DFT over y -> conj(probe) / conj(patch) -> f / prb
+//
+// Work is issued in chunks of scan positions so that the intermediate of a
+// chunk is still resident in the 256 MiB Infinity Cache when the second pass
+// reads it.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/ptycho_hip.h"
+#include "fft_core.hpp"
+
+using namespace pty;
+
+namespace {
+
+struct Geom {
+    int ptheta, nz, n, nscan, ndet, nprb, pad;
+};
+
+enum Mode { M_PLAIN = 0, M_FWD = 1, M_ADJ_OBJ = 2, M_ADJ_PRB = 3 };
+
+template <int N>
+struct ColCfg {
+    static constexpr int T = Plan<N>::T;
+    static constexpr int C0 = (256 / T) > 16 ? (256 / T) : 16;
+    static constexpr int C = C0 > N ? N : C0;   // detector columns per strip
+    static constexpr int NT = T * C;            // threads per workgroup
+};
+
+struct ColArgs {
+    const c32* src;     // FWD: object f; ADJ_*: chunk scratch (tile index p - p_begin); PLAIN: tiles
+    c32* dst;           // FWD: farplane g; ADJ_OBJ: object f; ADJ_PRB: probe; PLAIN: tiles
+    const c32* aux;     // FWD / ADJ_OBJ: probe; ADJ_PRB: object f
+    const float* scan;  // [ptheta][nscan][2]
+    const c32* table;   // exp(-2 pi i k / N)
+    Geom ge;
+    int p_begin, p_end; // flattened (angle * nscan + position) range of this launch
+    int ngroups;        // position groups; grid = nstrips * ngroups
+    int strip0, nstrips;
+};
+
+struct RowArgs {
+    const c32* src;
+    c32* dst;
+    const c32* table;
+    long long nrows;
+    int xa, xb;   // columns outside [xa, xb) are read as zero
+    int wa, wb;   // only columns in [wa, wb) are written
+};
+
+struct Pos {
+    int sy, sx;
+    float fy, fx;
+    bool valid, inside;
+};
+
+// modff split of one scan position -- kernels.cu:27-28,39
+__device__ __forceinline__ Pos decode_pos(const float* __restrict__ scan, int p, const Geom& ge) {
+    Pos q;
+    const float py = scan[2 * (size_t)p], px = scan[2 * (size_t)p + 1];
+    float iy, ix;
+    q.fy = modff(py, &iy);
+    q.fx = modff(px, &ix);
+    // the reference skips sx < 0 || sy < 0; non-finite positions are skipped too
+    q.valid = !(ix < 0.0f || iy < 0.0f) && (ix < 1.0e9f) && (iy < 1.0e9f) && (ix == ix) && (iy == iy);
+    q.sy = q.valid ? (int)iy : 0;
+    q.sx = q.valid ? (int)ix : 0;
+    q.inside = q.valid && (q.sy + ge.nprb + 1 <= ge.nz) && (q.sx + ge.nprb + 1 <= ge.n);
+    return q;
+}
+
+// kernels.cu:97-104 -- same taps, same left-to-right weight products
+__device__ __forceinline__ c32 bilerp(const c32* __restrict__ ft, int Y, int X, const Pos& q, const Geom& ge) {
+    const float wx0 = 1.0f - q.fx, wy0 = 1.0f - q.fy;
+    c32 f00, f01, f10, f11;
+    if (q.inside) {
+        const c32* p = ft + (size_t)Y * ge.n + X;
+        f00 = p[0]; f01 = p[1]; f10 = p[ge.n]; f11 = p[ge.n + 1];
+    } else {
+        const bool y0 = Y >= 0 && Y < ge.nz, y1 = Y + 1 >= 0 && Y + 1 < ge.nz;
+        const bool x0 = X >= 0 && X < ge.n, x1 = X + 1 >= 0 && X + 1 < ge.n;
+        const c32 z = c32{0.0f, 0.0f};
+        f00 = (y0 && x0) ? ft[(size_t)Y * ge.n + X] : z;
+        f01 = (y0 && x1) ? ft[(size_t)Y * ge.n + X + 1] : z;
+        f10 = (y1 && x0) ? ft[(size_t)(Y + 1) * ge.n + X] : z;
+        f11 = (y1 && x1) ? ft[(size_t)(Y + 1) * ge.n + X + 1] : z;
+    }
+    return f00 * wx0 * wy0 + f01 * q.fx * wy0 + f10 * wx0 * q.fy + f11 * q.fx * q.fy;
+}
+
+// ---------------------------------------------------------------------------
+// Column pass: DFT over y for a strip of C detector columns, fused with the
+// probe / object product.  Thread (c, j0) holds points y = j0 + b*T + t*N/R of
+// column x0 + c; LDS image is [y][c] (c fastest), conflict free in every step.
+// ---------------------------------------------------------------------------
+template <int N, int DIR, int MODE>
+__global__ __launch_bounds__(ColCfg<N>::NT) void k_cols(const ColArgs a) {
+    using P = Plan<N>;
+    using F = Fft<P, DIR>;
+    constexpr int E = P::E, T = P::T, C = ColCfg<N>::C, NT = ColCfg<N>::NT;
+    constexpr int LAST = P::NSTEP - 1;
+    __shared__ c32 lds[N * C];
+
+    const int tid = threadIdx.x;
+    const int c = tid % C, j0 = tid / C;
+    const int strip = blockIdx.x % a.nstrips, group = blockIdx.x / a.nstrips;
+    const int x0 = (a.strip0 + strip) * C;
+    const int x = x0 + c;
+    const Geom ge = a.ge;
+    const int ix = x - ge.pad;
+    const bool col_ok = ix >= 0 && ix < ge.nprb;
+    const float cinv = 1.0f / (float)N;   // kernels.cu:65
+
+    F fft;
+    fft.init(j0, a.table);
+
+    // slot -> y of the points this thread feeds into step 0 / receives from the last step
+    // (both are j0 + b*T + t*N/R with the step's own R; they may order slots differently)
+    c32 pr[E];   // FWD / ADJ_OBJ: c * probe strip; ADJ_PRB: gradient accumulators
+    int cur_t = -1;
+    const c32 zero = c32{0.0f, 0.0f};
+
+    auto flush_probe = [&](int t) {
+        // ADJ_PRB: add this workgroup's partial sums into prb[t]
+        constexpr int R = P::radix(LAST), Ns = P::ns(LAST);
+#pragma unroll
+        for (int b = 0; b < E / R; ++b) {
+            const int j = j0 + b * T;
+            const int base = (j / Ns) * Ns * R + (j % Ns);
+#pragma unroll
+            for (int tt = 0; tt < R; ++tt) {
+                const int iy = base + tt * Ns - ge.pad;
+                if (col_ok && iy >= 0 && iy < ge.nprb) {
+                    float* o = reinterpret_cast<float*>(a.dst + ((size_t)t * ge.nprb + iy) * ge.nprb + ix);
+                    const c32 s = pr[b * R + tt] * cinv;
+                    atomicAdd(o, s.x);
+                    atomicAdd(o + 1, s.y);
+                }
+            }
+        }
+    };
+
+    for (int p = a.p_begin + group; p < a.p_end; p += a.ngroups) {
+        const int t = p / ge.nscan;
+        if (MODE == M_FWD || MODE == M_ADJ_OBJ) {
+            if (t != cur_t) {
+                const c32* prb = a.aux + (size_t)t * ge.nprb * ge.nprb;
+                constexpr int R = (MODE == M_FWD) ? P::radix(0) : P::radix(LAST);
+                constexpr int Ns = (MODE == M_FWD) ? 1 : P::ns(LAST);
+#pragma unroll
+                for (int b = 0; b < E / R; ++b) {
+                    const int j = j0 + b * T;
+#pragma unroll
+                    for (int tt = 0; tt < R; ++tt) {
+                        const int y = (MODE == M_FWD) ? (j + tt * (N / R)) : ((j / Ns) * Ns * R + (j % Ns) + tt * Ns);
+                        const int iy = y - ge.pad;
+                        const bool ok = col_ok && iy >= 0 && iy < ge.nprb;
+                        pr[b * R + tt] = ok ? prb[(size_t)iy * ge.nprb + ix] * cinv : zero;
+                    }
+                }
+            }
+        } else if (MODE == M_ADJ_PRB) {
+            if (t != cur_t) {
+                if (cur_t >= 0) flush_probe(cur_t);
+#pragma unroll
+                for (int s = 0; s < E; ++s) pr[s] = zero;
+            }
+        }
+        cur_t = t;
+
+        Pos q;
+        if (MODE != M_PLAIN) {
+            q = decode_pos(a.scan, p, ge);
+            if (MODE != M_FWD && !q.valid) continue;   // uniform across the workgroup
+        }
+        const c32* ft = nullptr;   // object of this angle
+        if (MODE == M_FWD) ft = a.src + (size_t)t * ge.nz * ge.n;
+        if (MODE == M_ADJ_PRB) ft = a.aux + (size_t)t * ge.nz * ge.n;
+        const c32* tile_in = nullptr;
+        if (MODE == M_PLAIN) tile_in = a.src + (size_t)p * N * N;
+        if (MODE == M_ADJ_OBJ || MODE == M_ADJ_PRB) tile_in = a.src + (size_t)(p - a.p_begin) * N * N;
+
+        c32 v[E];
+        // ---- step 0 input ---------------------------------------------------
+        {
+            constexpr int R = P::radix(0);
+#pragma unroll
+            for (int b = 0; b < E / R; ++b)
+#pragma unroll
+                for (int tt = 0; tt < R; ++tt) {
+                    const int y = j0 + b * T + tt * (N / R);
+                    c32 val;
+                    if (MODE == M_FWD) {
+                        const int iy = y - ge.pad;
+                        const bool ok = q.valid && col_ok && iy >= 0 && iy < ge.nprb;
+                        val = ok ? cmul(pr[b * R + tt], bilerp(ft, q.sy + iy, q.sx + ix, q, ge)) : zero;
+                    } else {
+                        val = tile_in[(size_t)y * N + x];
+                    }
+                    v[b * R + tt] = val;
+                }
+        }
+        fft.template compute<0>(v);
+        if (P::NSTEP > 1) {
+            fft.template store<0>(v, j0, [&](int i, c32 val) { lds[i * C + c] = val; });
+            __syncthreads();
+            fft.template load<1>(v, j0, [&](int i) { return lds[i * C + c]; });
+            if (P::NSTEP > 2) {
+                __syncthreads();
+                fft.template compute<1>(v);
+                fft.template store<1>(v, j0, [&](int i, c32 val) { lds[i * C + c] = val; });
+                __syncthreads();
+                fft.template load<2>(v, j0, [&](int i) { return lds[i * C + c]; });
+            }
+            fft.template compute<LAST>(v);
+        }
+        // ---- last step output -----------------------------------------------
+        constexpr int RL = P::radix(LAST), NsL = P::ns(LAST);
+        if (MODE == M_FWD || MODE == M_PLAIN) {
+            c32* tile_out = a.dst + (size_t)p * N * N;
+            fft.template store<LAST>(v, j0, [&](int i, c32 val) { tile_out[(size_t)i * N + x] = val; });
+            if (P::NSTEP > 1) __syncthreads();   // lds is rewritten by the next position
+        } else if (MODE == M_ADJ_PRB) {
+#pragma unroll
+            for (int b = 0; b < E / RL; ++b) {
+                const int j = j0 + b * T;
+                const int base = (j / NsL) * NsL * RL + (j % NsL);
+#pragma unroll
+                for (int tt = 0; tt < RL; ++tt) {
+                    const int iy = base + tt * NsL - ge.pad;
+                    if (col_ok && iy >= 0 && iy < ge.nprb) {
+                        const c32 val = v[b * RL + brev(tt, ilog2(RL))];
+                        pr[b * RL + tt] += cmulc(val, bilerp(ft, q.sy + iy, q.sx + ix, q, ge));
+                    }
+                }
+            }
+            if (P::NSTEP > 1) __syncthreads();
+        } else {   // M_ADJ_OBJ: tile T[y][c] = conj(c*prb) * near, then 4-tap combine + atomics
+            if (P::NSTEP > 1) __syncthreads();   // everyone finished reading lds
+#pragma unroll
+            for (int b = 0; b < E / RL; ++b) {
+                const int j = j0 + b * T;
+                const int base = (j / NsL) * NsL * RL + (j % NsL);
+#pragma unroll
+                for (int tt = 0; tt < RL; ++tt) {
+                    const c32 val = v[b * RL + brev(tt, ilog2(RL))];
+                    const c32 w = pr[b * RL + tt];
+                    lds[(base + tt * NsL) * C + c] = c32{w.x * val.x + w.y * val.y, w.x * val.y - w.y * val.x};
+                }
+            }
+            __syncthreads();
+            // output pixel (yy, cc): yy in [0, nprb] (probe rows, +1), cc in [0, C] of this strip
+            const float wx0 = 1.0f - q.fx, wy0 = 1.0f - q.fy;
+            c32* fo = a.dst + (size_t)t * ge.nz * ge.n;
+            const int nout = (ge.nprb + 1) * (C + 1);
+            for (int o = tid; o < nout; o += NT) {
+                const int yy = o / (C + 1), cc = o % (C + 1);
+                const int y = yy + ge.pad;   // nearplane row of tap (0,0)
+                // taps: T[y][cc], T[y][cc-1], T[y-1][cc], T[y-1][cc-1]; zero outside the strip / tile.
+                // T is zero by construction outside the probe window (pr = 0 there).
+                const bool r0 = yy < ge.nprb, r1 = yy >= 1;
+                const bool c0 = cc < C, c1 = cc >= 1;
+                const c32 t00 = (r0 && c0) ? lds[y * C + cc] : zero;
+                const c32 t01 = (r0 && c1) ? lds[y * C + cc - 1] : zero;
+                const c32 t10 = (r1 && c0) ? lds[(y - 1) * C + cc] : zero;
+                const c32 t11 = (r1 && c1) ? lds[(y - 1) * C + cc - 1] : zero;
+                const c32 s = t00 * wx0 * wy0 + t01 * q.fx * wy0 + t10 * wx0 * q.fy + t11 * q.fx * q.fy;
+                const int Y = q.sy + yy, X = q.sx + (x0 - ge.pad) + cc;
+                if (Y >= 0 && Y < ge.nz && X >= 0 && X < ge.n && (x0 - ge.pad + cc) >= 0 && (x0 - ge.pad + cc) <= ge.nprb) {
+                    float* op = reinterpret_cast<float*>(fo + (size_t)Y * ge.n + X);
+                    atomicAdd(op, s.x);
+                    atomicAdd(op + 1, s.y);
+                }
+            }
+            __syncthreads();
+        }
+    }
+    if (MODE == M_ADJ_PRB && cur_t >= 0) flush_probe(cur_t);
+}
+
+// ---------------------------------------------------------------------------
+// Row pass: DFT over x of contiguous rows, B = 256/T rows per workgroup step.
+// ---------------------------------------------------------------------------
+template <int N, int DIR>
+__global__ __launch_bounds__(256) void k_rows(const RowArgs a) {
+    using P = Plan<N>;
+    using F = Fft<P, DIR>;
+    using L = RowLds<N>;
+    constexpr int E = P::E, T = P::T, B = 256 / T;
+    constexpr int LAST = P::NSTEP - 1;
+    __shared__ c32 lds[P::NSTEP > 1 ? B * L::FS : 1];
+
+    const int tid = threadIdx.x;
+    const int f = tid / T, j0 = tid % T;
+    F fft;
+    fft.init(j0, a.table);
+    const c32 zero = c32{0.0f, 0.0f};
+    const long long nb = (a.nrows + B - 1) / B;
+    for (long long batch = blockIdx.x; batch < nb; batch += gridDim.x) {
+        const long long r = batch * B + f;
+        const bool ok = r < a.nrows;
+        const c32* srow = a.src + (size_t)r * N;
+        c32* drow = a.dst + (size_t)r * N;
+        c32 v[E];
+        fft.template load<0>(v, j0, [&](int i) { return (ok && i >= a.xa && i < a.xb) ? srow[i] : zero; });
+        fft.template compute<0>(v);
+        if (P::NSTEP > 1) {
+            fft.template store<0>(v, j0, [&](int i, c32 val) { lds[L::at(f, i)] = val; });
+            __syncthreads();
+            fft.template load<1>(v, j0, [&](int i) { return lds[L::at(f, i)]; });
+            if (P::NSTEP > 2) {
+                __syncthreads();
+                fft.template compute<1>(v);
+                fft.template store<1>(v, j0, [&](int i, c32 val) { lds[L::at(f, i)] = val; });
+                __syncthreads();
+                fft.template load<2>(v, j0, [&](int i) { return lds[L::at(f, i)]; });
+            }
+            fft.template compute<LAST>(v);
+        }
+        fft.template store<LAST>(v, j0, [&](int i, c32 val) {
+            if (ok && i >= a.wa && i < a.wb) drow[i] = val;
+        });
+        if (P::NSTEP > 1) __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------
+thread_local std::string g_err;
+
+// kernel ids for the in-library profiler (ptycho_profile_read)
+enum { K_COLS_FWD = 0, K_ROWS_FWD = 1, K_ROWS_INV = 2, K_COLS_ADJ_OBJ = 3, K_COLS_ADJ_PRB = 4, K_COLS_PLAIN = 5, K_COUNT = 6 };
+
+
+int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                   \
+    do {                                                                                \
+        hipError_t e_ = (expr);                                                         \
+        if (e_ != hipSuccess)                                                           \
+            return fail(PTYCHO_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+}  // namespace
+
+struct ptycho_handle_s {
+    Geom ge;
+    c32* table = nullptr;     // exp(-2 pi i k / ndet)
+    c32* scratch = nullptr;   // chunk * ndet^2 complex64
+    long long chunk = 0;      // positions per launch pair
+    int device = 0;
+    int n_cu = 256;
+    bool freed = false;
+    bool profile = false;
+    struct Span { int kid; hipEvent_t a, b; };
+    std::vector<Span> spans;
+};
+
+namespace {
+
+long long default_chunk(const Geom& ge) {
+    const char* env = std::getenv("PTYCHO_HIP_CHUNK");
+    if (env && std::atoll(env) > 0) return std::atoll(env);
+    // keep one chunk's intermediate (ndet^2 * 8 B per position) around 64 MiB
+    const long long per = (long long)ge.ndet * ge.ndet * 8;
+    long long c = (64ll << 20) / per;
+    if (c < 16) c = 16;
+    return c;
+}
+
+int alloc_scratch(ptycho_handle h) {
+    if (h->scratch) {
+        HIP_TRY(hipFree(h->scratch));
+        h->scratch = nullptr;
+    }
+    const long long total = (long long)h->ge.ptheta * h->ge.nscan;
+    long long c = h->chunk < total ? h->chunk : total;
+    if (c < 1) c = 1;
+    HIP_TRY(hipMalloc((void**)&h->scratch, (size_t)c * h->ge.ndet * h->ge.ndet * sizeof(c32)));
+    return PTYCHO_OK;
+}
+
+template <int N, int DIR, int MODE>
+int launch_cols(ptycho_handle h, ColArgs a, hipStream_t st) {
+    using CC = ColCfg<N>;
+    const int np = a.p_end - a.p_begin;
+    if (np <= 0 || a.nstrips <= 0) return PTYCHO_OK;
+    int target = h->n_cu * 8;
+    int ng = target / a.nstrips;
+    if (ng < 1) ng = 1;
+    if (ng > np) ng = np;
+    a.ngroups = ng;
+    constexpr int kid = MODE == M_FWD ? K_COLS_FWD : MODE == M_ADJ_OBJ ? K_COLS_ADJ_OBJ : MODE == M_ADJ_PRB ? K_COLS_ADJ_PRB : K_COLS_PLAIN;
+    ptycho_handle_s::Span sp{kid, nullptr, nullptr};
+    if (h->profile) { HIP_TRY(hipEventCreate(&sp.a)); HIP_TRY(hipEventCreate(&sp.b)); HIP_TRY(hipEventRecord(sp.a, st)); }
+    hipLaunchKernelGGL((k_cols<N, DIR, MODE>), dim3((unsigned)(a.nstrips * ng)), dim3(CC::NT), 0, st, a);
+    HIP_TRY(hipGetLastError());
+    if (h->profile) { HIP_TRY(hipEventRecord(sp.b, st)); h->spans.push_back(sp); }
+    return PTYCHO_OK;
+}
+
+template <int N, int DIR>
+int launch_rows(ptycho_handle h, RowArgs a, hipStream_t st) {
+    constexpr int B = 256 / Plan<N>::T;
+    if (a.nrows <= 0) return PTYCHO_OK;
+    long long nb = (a.nrows + B - 1) / B;
+    long long grid = nb < (long long)h->n_cu * 8 ? nb : (long long)h->n_cu * 8;
+    ptycho_handle_s::Span sp{DIR < 0 ? K_ROWS_FWD : K_ROWS_INV, nullptr, nullptr};
+    if (h->profile) { HIP_TRY(hipEventCreate(&sp.a)); HIP_TRY(hipEventCreate(&sp.b)); HIP_TRY(hipEventRecord(sp.a, st)); }
+    hipLaunchKernelGGL((k_rows<N, DIR>), dim3((unsigned)grid), dim3(256), 0, st, a);
+    HIP_TRY(hipGetLastError());
+    if (h->profile) { HIP_TRY(hipEventRecord(sp.b, st)); h->spans.push_back(sp); }
+    return PTYCHO_OK;
+}
+
+template <int N>
+void strip_range(const Geom& ge, int& strip0, int& nstrips) {
+    constexpr int C = ColCfg<N>::C;
+    strip0 = ge.pad / C;
+    const int last = (ge.pad + ge.nprb - 1) / C;
+    nstrips = last - strip0 + 1;
+}
+
+template <int N>
+int do_fwd(ptycho_handle h, c32* g, const c32* f, const float* scan, const c32* prb, hipStream_t st) {
+    constexpr int C = ColCfg<N>::C;
+    const Geom& ge = h->ge;
+    const long long total = (long long)ge.ptheta * ge.nscan;
+    int strip0, nstrips;
+    strip_range<N>(ge, strip0, nstrips);
+    for (long long p0 = 0; p0 < total; p0 += h->chunk) {
+        const long long p1 = p0 + h->chunk < total ? p0 + h->chunk : total;
+        ColArgs ca{};
+        ca.src = f; ca.dst = g; ca.aux = prb; ca.scan = scan; ca.table = h->table; ca.ge = ge;
+        ca.p_begin = (int)p0; ca.p_end = (int)p1; ca.strip0 = strip0; ca.nstrips = nstrips;
+        int rc = launch_cols<N, -1, M_FWD>(h, ca, st);
+        if (rc) return rc;
+        RowArgs ra{};
+        ra.src = g + (size_t)p0 * N * N; ra.dst = g + (size_t)p0 * N * N; ra.table = h->table;
+        ra.nrows = (p1 - p0) * N; ra.xa = strip0 * C; ra.xb = (strip0 + nstrips) * C; ra.wa = 0; ra.wb = N;
+        rc = launch_rows<N, -1>(h, ra, st);
+        if (rc) return rc;
+    }
+    return PTYCHO_OK;
+}
+
+template <int N>
+int do_adj(ptycho_handle h, c32* f, const c32* g, const float* scan, c32* prb, int flg, hipStream_t st) {
+    constexpr int C = ColCfg<N>::C;
+    const Geom& ge = h->ge;
+    const long long total = (long long)ge.ptheta * ge.nscan;
+    int strip0, nstrips;
+    strip_range<N>(ge, strip0, nstrips);
+    for (long long p0 = 0; p0 < total; p0 += h->chunk) {
+        const long long p1 = p0 + h->chunk < total ? p0 + h->chunk : total;
+        RowArgs ra{};
+        ra.src = g + (size_t)p0 * N * N; ra.dst = h->scratch; ra.table = h->table;
+        ra.nrows = (p1 - p0) * N; ra.xa = 0; ra.xb = N; ra.wa = strip0 * C; ra.wb = (strip0 + nstrips) * C;
+        int rc = launch_rows<N, +1>(h, ra, st);
+        if (rc) return rc;
+        ColArgs ca{};
+        ca.src = h->scratch; ca.scan = scan; ca.table = h->table; ca.ge = ge;
+        ca.p_begin = (int)p0; ca.p_end = (int)p1; ca.strip0 = strip0; ca.nstrips = nstrips;
+        if (flg == 0) {
+            ca.dst = f; ca.aux = prb;
+            rc = launch_cols<N, +1, M_ADJ_OBJ>(h, ca, st);
+        } else {
+            ca.dst = prb; ca.aux = f;
+            rc = launch_cols<N, +1, M_ADJ_PRB>(h, ca, st);
+        }
+        if (rc) return rc;
+    }
+    return PTYCHO_OK;
+}
+
+template <int N>
+int do_fft2(ptycho_handle h, c32* dst, const c32* src, long long nbatch, int dir, hipStream_t st) {
+    constexpr int C = ColCfg<N>::C;
+    RowArgs ra{};
+    ra.src = src; ra.dst = dst; ra.table = h->table; ra.nrows = nbatch * N;
+    ra.xa = 0; ra.xb = N; ra.wa = 0; ra.wb = N;
+    int rc = dir < 0 ? launch_rows<N, -1>(h, ra, st) : launch_rows<N, +1>(h, ra, st);
+    if (rc) return rc;
+    // column pass in place, in slices small enough for 32-bit position indices
+    const long long slice = 1 << 20;
+    for (long long b0 = 0; b0 < nbatch; b0 += slice) {
+        const long long b1 = b0 + slice < nbatch ? b0 + slice : nbatch;
+        ColArgs ca{};
+        ca.src = dst + (size_t)b0 * N * N; ca.dst = dst + (size_t)b0 * N * N; ca.table = h->table; ca.ge = h->ge;
+        ca.p_begin = 0; ca.p_end = (int)(b1 - b0); ca.strip0 = 0; ca.nstrips = N / C;
+        rc = dir < 0 ? launch_cols<N, -1, M_PLAIN>(h, ca, st) : launch_cols<N, +1, M_PLAIN>(h, ca, st);
+        if (rc) return rc;
+    }
+    return PTYCHO_OK;
+}
+
+#define PTY_DISPATCH(N_, CALL)                                   \
+    switch (N_) {                                                \
+        case 16: { constexpr int NN = 16; return CALL; }         \
+        case 32: { constexpr int NN = 32; return CALL; }         \
+        case 64: { constexpr int NN = 64; return CALL; }         \
+        case 128: { constexpr int NN = 128; return CALL; }       \
+        case 256: { constexpr int NN = 256; return CALL; }       \
+        case 512: { constexpr int NN = 512; return CALL; }       \
+        case 1024: { constexpr int NN = 1024; return CALL; }     \
+        default: return fail(PTYCHO_ERR_ARG, "ndet must be a power of two in [16, 1024]"); \
+    }
+
+int check_handle(ptycho_handle h) {
+    if (!h) return fail(PTYCHO_ERR_ARG, "null handle");
+    if (h->freed) return fail(PTYCHO_ERR_FREED, "handle used after ptycho_free");
+    return PTYCHO_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* ptycho_last_error(void) { return g_err.c_str(); }
+const char* ptycho_version(void) { return "ptychohip 0.1 (gfx950)"; }
+
+int ptycho_create(ptycho_handle* out, size_t ptheta, size_t nz, size_t n, size_t nscan, size_t ndet, size_t nprb) {
+    if (!out) return fail(PTYCHO_ERR_ARG, "out is null");
+    *out = nullptr;
+    if (ptheta == 0 || nz == 0 || n == 0 || nscan == 0 || ndet == 0 || nprb == 0)
+        return fail(PTYCHO_ERR_ARG, "all sizes must be positive");
+    if (ndet < 16 || ndet > 1024 || (ndet & (ndet - 1)) != 0)
+        return fail(PTYCHO_ERR_ARG, "ndet must be a power of two in [16, 1024]");
+    if (nprb > ndet) return fail(PTYCHO_ERR_ARG, "nprb must be <= ndet");
+    if (ptheta * nscan > (size_t)0x7fffffff / 2 || nz > 65536 * 4 || n > 65536 * 4)
+        return fail(PTYCHO_ERR_ARG, "problem too large for 32-bit position indices");
+    ptycho_handle h = new ptycho_handle_s();
+    h->ge = Geom{(int)ptheta, (int)nz, (int)n, (int)nscan, (int)ndet, (int)nprb, (int)((ndet - nprb) / 2)};
+    hipError_t e = hipGetDevice(&h->device);
+    if (e != hipSuccess) {
+        delete h;
+        return fail(PTYCHO_ERR_HIP, std::string("hipGetDevice: ") + hipGetErrorString(e));
+    }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, h->device) == hipSuccess && prop.multiProcessorCount > 0)
+        h->n_cu = prop.multiProcessorCount;
+    std::vector<c32> tab(ndet);
+    for (size_t k = 0; k < ndet; ++k) {
+        const double ang = -2.0 * M_PI * (double)k / (double)ndet;
+        tab[k] = c32{(float)std::cos(ang), (float)std::sin(ang)};
+    }
+    e = hipMalloc((void**)&h->table, ndet * sizeof(c32));
+    if (e == hipSuccess) e = hipMemcpy(h->table, tab.data(), ndet * sizeof(c32), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        if (h->table) (void)hipFree(h->table);
+        delete h;
+        return fail(PTYCHO_ERR_HIP, std::string("twiddle table: ") + hipGetErrorString(e));
+    }
+    h->chunk = default_chunk(h->ge);
+    int rc = alloc_scratch(h);
+    if (rc) {
+        (void)hipFree(h->table);
+        delete h;
+        return rc;
+    }
+    *out = h;
+    return PTYCHO_OK;
+}
+
+int ptycho_free(ptycho_handle h) {
+    if (!h) return fail(PTYCHO_ERR_ARG, "null handle");
+    if (!h->freed) {
+        h->freed = true;
+        if (h->table) (void)hipFree(h->table);
+        if (h->scratch) (void)hipFree(h->scratch);
+        h->table = nullptr;
+        h->scratch = nullptr;
+    }
+    return PTYCHO_OK;
+}
+
+int ptycho_destroy(ptycho_handle h) {
+    if (!h) return PTYCHO_OK;
+    ptycho_free(h);
+    delete h;
+    return PTYCHO_OK;
+}
+
+long long ptycho_get(ptycho_handle h, int which) {
+    if (!h) return -1;
+    switch (which) {
+        case 0: return h->ge.ptheta;
+        case 1: return h->ge.nz;
+        case 2: return h->ge.n;
+        case 3: return h->ge.nscan;
+        case 4: return h->ge.ndet;
+        case 5: return h->ge.nprb;
+        case 100: return h->chunk;
+        default: return -1;
+    }
+}
+
+int ptycho_set_option(ptycho_handle h, const char* name, long long value) {
+    int rc = check_handle(h);
+    if (rc) return rc;
+    if (!name) return fail(PTYCHO_ERR_ARG, "null option name");
+    if (std::strcmp(name, "chunk") == 0) {
+        h->chunk = value > 0 ? value : default_chunk(h->ge);
+        HIP_TRY(hipDeviceSynchronize());
+        return alloc_scratch(h);
+    }
+    return fail(PTYCHO_ERR_ARG, std::string("unknown option ") + name);
+}
+
+int ptycho_profile(ptycho_handle h, int enable) {
+    int rc = check_handle(h);
+    if (rc) return rc;
+    h->profile = enable != 0;
+    return PTYCHO_OK;
+}
+
+int ptycho_profile_read(ptycho_handle h, double* ms, long long* launches, int n) {
+    int rc = check_handle(h);
+    if (rc) return rc;
+    if (!ms || !launches || n < K_COUNT) return fail(PTYCHO_ERR_ARG, "need arrays of at least 6 entries");
+    for (int i = 0; i < n; ++i) { ms[i] = 0.0; launches[i] = 0; }
+    for (auto& sp : h->spans) {
+        HIP_TRY(hipEventSynchronize(sp.b));
+        float t = 0.f;
+        HIP_TRY(hipEventElapsedTime(&t, sp.a, sp.b));
+        ms[sp.kid] += t;
+        launches[sp.kid] += 1;
+        (void)hipEventDestroy(sp.a);
+        (void)hipEventDestroy(sp.b);
+    }
+    h->spans.clear();
+    return PTYCHO_OK;
+}
+
+int ptycho_fwd(ptycho_handle h, void* g, const void* f, const void* scan, const void* prb, void* stream) {
+    int rc = check_handle(h);
+    if (rc) return rc;
+    if (!g || !f || !scan || !prb) return fail(PTYCHO_ERR_ARG, "null operand");
+    hipStream_t st = (hipStream_t)stream;
+    PTY_DISPATCH(h->ge.ndet, (do_fwd<NN>(h, (c32*)g, (const c32*)f, (const float*)scan, (const c32*)prb, st)));
+}
+
+int ptycho_adj(ptycho_handle h, void* f, const void* g, const void* scan, void* prb, int flg, void* stream) {
+    int rc = check_handle(h);
+    if (rc) return rc;
+    if (!g || !f || !scan || !prb) return fail(PTYCHO_ERR_ARG, "null operand");
+    if (flg != 0 && flg != 1) return fail(PTYCHO_ERR_ARG, "flg must be 0 (object) or 1 (probe)");
+    hipStream_t st = (hipStream_t)stream;
+    PTY_DISPATCH(h->ge.ndet, (do_adj<NN>(h, (c32*)f, (const c32*)g, (const float*)scan, (c32*)prb, flg, st)));
+}
+
+int ptycho_fft2(ptycho_handle h, void* dst, const void* src, size_t nbatch, int dir, void* stream) {
+    int rc = check_handle(h);
+    if (rc) return rc;
+    if (!dst || !src) return fail(PTYCHO_ERR_ARG, "null operand");
+    if (dir != -1 && dir != 1) return fail(PTYCHO_ERR_ARG, "dir must be -1 (forward) or +1 (inverse)");
+    if (nbatch == 0) return PTYCHO_OK;
+    hipStream_t st = (hipStream_t)stream;
+    PTY_DISPATCH(h->ge.ndet, (do_fft2<NN>(h, (c32*)dst, (const c32*)src, (long long)nbatch, dir, st)));
+}
+
+}  // extern "C"

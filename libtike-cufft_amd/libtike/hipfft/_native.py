@@ -1,0 +1,62 @@
+"""ctypes binding of ``libptychohip.so`` (C ABI: ``include/ptycho_hip.h``).
+
+Replaces the SWIG / pybind11 extension module ``libtike.cufft.ptychofft``
+(``/root/reference/src/cuda/swig/ptychofft.i:1-26``,
+``/root/reference/src/cuda/pybind11/ptychofft.cxx:1-27``).  There is no
+fallback: if the shared library is missing this module raises at import.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libptychohip.so")
+
+#: every symbol ``include/ptycho_hip.h`` declares
+SYMBOLS = ("ptycho_create", "ptycho_free", "ptycho_destroy", "ptycho_get",
+           "ptycho_fwd", "ptycho_adj", "ptycho_fft2", "ptycho_set_option",
+           "ptycho_profile", "ptycho_profile_read",
+           "ptycho_last_error", "ptycho_version")
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        "libtike.hipfft: %s not found -- build it with "
+        "`make -C libtike-cufft_amd/csrc` (or `python -c 'import "
+        "__graft_entry__ as g; g.build()'`). There is no CPU fallback." % LIB_PATH)
+
+lib = ctypes.CDLL(LIB_PATH)
+
+_vp, _sz, _i, _ll = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_longlong
+
+
+def _sig(name, res, *args):
+    fn = getattr(lib, name)
+    fn.restype = res
+    fn.argtypes = list(args)
+    return fn
+
+
+create = _sig("ptycho_create", _i, ctypes.POINTER(_vp), _sz, _sz, _sz, _sz, _sz, _sz)
+free = _sig("ptycho_free", _i, _vp)
+destroy = _sig("ptycho_destroy", _i, _vp)
+get = _sig("ptycho_get", _ll, _vp, _i)
+fwd = _sig("ptycho_fwd", _i, _vp, _vp, _vp, _vp, _vp, _vp)
+adj = _sig("ptycho_adj", _i, _vp, _vp, _vp, _vp, _vp, _i, _vp)
+fft2 = _sig("ptycho_fft2", _i, _vp, _vp, _vp, _sz, _i, _vp)
+set_option = _sig("ptycho_set_option", _i, _vp, ctypes.c_char_p, _ll)
+profile = _sig("ptycho_profile", _i, _vp, _i)
+profile_read = _sig("ptycho_profile_read", _i, _vp, ctypes.POINTER(ctypes.c_double),
+                    ctypes.POINTER(_ll), _i)
+KERNEL_NAMES = ("k_cols<FWD>", "k_rows<fwd>", "k_rows<inv>", "k_cols<ADJ_OBJ>",
+                "k_cols<ADJ_PRB>", "k_cols<PLAIN>")
+last_error = _sig("ptycho_last_error", ctypes.c_char_p)
+version = _sig("ptycho_version", ctypes.c_char_p)
+
+
+class PtychoHipError(RuntimeError):
+    pass
+
+
+def check(rc):
+    if rc != 0:
+        raise PtychoHipError("libptychohip error %d: %s"
+                             % (rc, last_error().decode("utf-8", "replace")))

@@ -1,0 +1,480 @@
+"""Ptychography operators and CG solver on MI355X (HIP), keeping the Python
+operator API of ``libtike.cufft`` (``/root/reference/src/libtike/cufft/ptycho.py``).
+
+Device arrays are ``torch`` tensors on the current ROCm device (the reference
+uses CuPy arrays); torch is used for allocation, elementwise glue and
+``torch.distributed`` only -- the operators themselves are the HIP kernels behind
+``libptychohip.so`` (C ABI in ``include/ptycho_hip.h``).  There is no CPU path:
+importing this module without the shared library raises.
+
+Solvers are context managers::
+
+    with CGPtychoSolver(nscan, nprb, ndet, ptheta, nz, n) as slv:
+        result = slv.run_batch(data, psi, scan, probe, piter=50)
+"""
+import ctypes
+import warnings
+
+import numpy as np
+import torch
+
+from . import _native as nat
+
+__all__ = ["PtychoHIP", "PtychoCuFFT", "CGPtychoSolver",
+           "register_translation_batch", "TorchArrayModule"]
+
+
+class TorchArrayModule:
+    """Minimal ``array_module`` hook (``ptycho.py:55`` of the reference exposes
+    ``cp``): what a host framework needs to create device arrays."""
+    complex64, float32, float64 = torch.complex64, torch.float32, torch.float64
+
+    @staticmethod
+    def _dev():
+        return torch.device("cuda", torch.cuda.current_device())
+
+    @classmethod
+    def asarray(cls, x, dtype=None):
+        if isinstance(x, torch.Tensor):
+            return x.to(device=cls._dev(), dtype=dtype) if dtype else x.to(cls._dev())
+        return torch.as_tensor(np.ascontiguousarray(x), dtype=dtype, device=cls._dev())
+
+    array = asarray
+
+    @classmethod
+    def zeros(cls, shape, dtype=torch.float32):
+        return torch.zeros(tuple(shape), dtype=_tdtype(dtype), device=cls._dev())
+
+    @classmethod
+    def ones(cls, shape, dtype=torch.float32):
+        return torch.ones(tuple(shape), dtype=_tdtype(dtype), device=cls._dev())
+
+    @classmethod
+    def empty(cls, shape, dtype=torch.float32):
+        return torch.empty(tuple(shape), dtype=_tdtype(dtype), device=cls._dev())
+
+
+def _tdtype(d):
+    if isinstance(d, torch.dtype):
+        return d
+    return {"complex64": torch.complex64, "float32": torch.float32,
+            "float64": torch.float64, "complex128": torch.complex128}[np.dtype(d).name]
+
+
+def _asnumpy(x):
+    return x.detach().cpu().numpy() if isinstance(x, torch.Tensor) else np.asarray(x)
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr())
+
+
+class PtychoHIP:
+    """Forward / adjoint ptychography operators (``PtychoCuFFT`` of the
+    reference, ``ptycho.py:34-162``).
+
+    Attributes
+    ----------
+    nscan : int   scan positions per angular view
+    nprb : int    probe is ``nprb x nprb``
+    ndet : int    detector is ``ndet x ndet`` (power of two, 16..1024)
+    ptheta : int  angular views processed per call
+    n, nz : int   object width, height
+    """
+
+    array_module = TorchArrayModule
+    asnumpy = staticmethod(_asnumpy)
+
+    def __init__(self, nscan, probe_shape, detector_shape, ntheta, nz, n):
+        # argument order of ptycho.py:58-60 -> native (ptheta, nz, n, nscan, ndet, nprb)
+        if not torch.cuda.is_available():
+            raise RuntimeError("libtike.hipfft needs a ROCm GPU; there is no CPU path")
+        self._h = ctypes.c_void_p()
+        nat.check(nat.create(ctypes.byref(self._h), ntheta, nz, n, nscan,
+                             detector_shape, probe_shape))
+        self._device = torch.device("cuda", torch.cuda.current_device())
+
+    # read-only size attributes of the native object (swig/ptychofft.i:11-16)
+    ptheta = property(lambda self: int(nat.get(self._h, 0)))
+    nz = property(lambda self: int(nat.get(self._h, 1)))
+    n = property(lambda self: int(nat.get(self._h, 2)))
+    nscan = property(lambda self: int(nat.get(self._h, 3)))
+    ndet = property(lambda self: int(nat.get(self._h, 4)))
+    nprb = property(lambda self: int(nat.get(self._h, 5)))
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, type, value, traceback):
+        self.free()
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h is not None and h.value:
+            try:
+                nat.destroy(h)
+            except Exception:
+                pass
+            self._h = None
+
+    def free(self):
+        """Release device scratch; idempotent (``ptychofft.cu:49-57``)."""
+        if self._h is not None and self._h.value:
+            nat.check(nat.free(self._h))
+
+    def set_chunk(self, positions):
+        """Positions per launch pair (0 = default, about 64 MiB of farplane)."""
+        nat.check(nat.set_option(self._h, b"chunk", int(positions)))
+
+    def profile(self, enable=True):
+        """Bracket every kernel launch with HIP events (bench.py's live timing)."""
+        nat.check(nat.profile(self._h, int(bool(enable))))
+
+    def profile_read(self):
+        """``{kernel: (total_ms, launches)}`` since the last read; waits for them."""
+        ms = (ctypes.c_double * 6)()
+        cnt = (ctypes.c_longlong * 6)()
+        nat.check(nat.profile_read(self._h, ms, cnt, 6))
+        return {k: (ms[i], int(cnt[i])) for i, k in enumerate(nat.KERNEL_NAMES) if cnt[i]}
+
+    # -- helpers -------------------------------------------------------------
+    def _operand(self, x, dtype, shape, name):
+        assert x.dtype == dtype, f"{name}: {x.dtype}"
+        if not x.is_cuda:
+            raise ValueError(f"{name} must be a device tensor")
+        if tuple(x.shape) != tuple(shape):
+            raise ValueError(f"{name}: shape {tuple(x.shape)} != expected {tuple(shape)}")
+        return x if x.is_contiguous() else x.contiguous()
+
+    # -- operators (ptycho.py:80-123) ---------------------------------------
+    def fwd(self, psi, scan, probe):
+        """Ptychography transform (FQ)."""
+        psi = self._operand(psi, torch.complex64, (self.ptheta, self.nz, self.n), "psi")
+        scan = self._operand(scan, torch.float32, (self.ptheta, self.nscan, 2), "scan")
+        probe = self._operand(probe, torch.complex64, (self.ptheta, self.nprb, self.nprb), "probe")
+        farplane = torch.empty((self.ptheta, self.nscan, self.ndet, self.ndet),
+                               dtype=torch.complex64, device=psi.device)
+        nat.check(nat.fwd(self._h, _ptr(farplane), _ptr(psi), _ptr(scan), _ptr(probe), _stream()))
+        return farplane
+
+    def adj(self, farplane, scan, probe):
+        """Adjoint ptychography transform (Q*F*)."""
+        farplane = self._operand(farplane, torch.complex64,
+                                 (self.ptheta, self.nscan, self.ndet, self.ndet), "farplane")
+        scan = self._operand(scan, torch.float32, (self.ptheta, self.nscan, 2), "scan")
+        probe = self._operand(probe, torch.complex64, (self.ptheta, self.nprb, self.nprb), "probe")
+        psi = torch.zeros((self.ptheta, self.nz, self.n), dtype=torch.complex64,
+                          device=farplane.device)
+        nat.check(nat.adj(self._h, _ptr(psi), _ptr(farplane), _ptr(scan), _ptr(probe), 0, _stream()))
+        return psi
+
+    def adj_probe(self, farplane, scan, psi):
+        """Adjoint ptychography probe transform (O*F*), object is fixed."""
+        farplane = self._operand(farplane, torch.complex64,
+                                 (self.ptheta, self.nscan, self.ndet, self.ndet), "farplane")
+        scan = self._operand(scan, torch.float32, (self.ptheta, self.nscan, 2), "scan")
+        psi = self._operand(psi, torch.complex64, (self.ptheta, self.nz, self.n), "psi")
+        probe = torch.zeros((self.ptheta, self.nprb, self.nprb), dtype=torch.complex64,
+                            device=farplane.device)
+        nat.check(nat.adj(self._h, _ptr(psi), _ptr(farplane), _ptr(scan), _ptr(probe), 1, _stream()))
+        return probe
+
+    def fft2(self, x, inverse=False, out=None):
+        """Unnormalised batched 2-D DFT of ``[..., ndet, ndet]`` complex64 tiles
+        (the cuFFT plan of ``ptychofft.cu:14-20``)."""
+        assert x.dtype == torch.complex64 and x.shape[-1] == x.shape[-2] == self.ndet
+        x = x.contiguous()
+        out = torch.empty_like(x) if out is None else out
+        nb = x.numel() // (self.ndet * self.ndet)
+        nat.check(nat.fft2(self._h, _ptr(out), _ptr(x), nb, 1 if inverse else -1, _stream()))
+        return out
+
+    # -- host batching (ptycho.py:70-78, 91-95, 108-111, 125-129) -----------
+    def _batch(self, function, output, *inputs):
+        """NumPy in / NumPy out, one angular partition of ``ptheta`` views at a
+        time (the reference uploads slices of length 1, which is only right for
+        ``ptheta == 1``; here the slice length is ``ptheta``)."""
+        xp = self.array_module
+        step = self.ptheta
+        for ids in range(0, inputs[0].shape[0] - step + 1, step):
+            dev = [xp.asarray(x[ids:ids + step]) for x in inputs]
+            output[ids:ids + step] = self.asnumpy(function(*dev))
+        return output
+
+    def fwd_ptycho_batch(self, psi, scan, probe):
+        data = np.zeros([scan.shape[0], self.nscan, self.ndet, self.ndet], dtype="complex64")
+        return self._batch(self.fwd, data, psi, scan, _single_mode(probe))
+
+    def adj_ptycho_batch(self, farplane, scan, probe):
+        psi = np.zeros([scan.shape[0], self.nz, self.n], dtype="complex64")
+        return self._batch(self.adj, psi, farplane, scan, _single_mode(probe))
+
+    def adj_ptycho_batch_prb(self, farplane, scan, psi):
+        probe = np.zeros([scan.shape[0], self.nprb, self.nprb], dtype="complex64")
+        return self._batch(self.adj_probe, probe, farplane, scan, psi)
+
+    def run(self, data, psi, scan, probe, **kwargs):
+        raise NotImplementedError("Cannot run a base class.")
+
+    def run_batch(self, data, psi, scan, probe, **kwargs):
+        """Run by dividing the work into angular partitions (``ptycho.py:135-162``).
+        NumPy in / NumPy out; ``scan`` updates are not returned and remainder
+        angles are dropped, as in the reference."""
+        assert probe.ndim == 4, "probe needs 4 dimensions, not %d" % probe.ndim
+        xp = self.array_module
+        psi = psi.copy()
+        probe = probe.copy()
+        for k in range(0, scan.shape[0] // self.ptheta):
+            ids = np.arange(k * self.ptheta, (k + 1) * self.ptheta)
+            result = self.run(xp.asarray(data[ids]), xp.asarray(psi[ids]),
+                              xp.asarray(scan[ids]), xp.asarray(probe[ids]), **kwargs)
+            psi[ids] = self.asnumpy(result["psi"])
+            probe[ids] = self.asnumpy(result["probe"])
+        return {"psi": psi, "probe": probe}
+
+
+def _single_mode(probe):
+    """The ``*_batch`` wrappers accept a ``[ntheta,1,nprb,nprb]`` probe
+    (``/root/reference/tests/test_adjoint.py:24,44``): the slice keeps its memory
+    layout and the native side reads it as ``[ntheta,nprb,nprb]``."""
+    probe = np.asarray(probe)
+    if probe.ndim == 4:
+        assert probe.shape[1] == 1, "the *_batch wrappers take one probe mode"
+        return probe[:, 0]
+    return probe
+
+
+#: drop-in name of the reference class
+PtychoCuFFT = PtychoHIP
+
+
+# ---------------------------------------------------------------------------
+# position registration (ptycho.py:163-248)
+# ---------------------------------------------------------------------------
+def _upsampled_dft_batch(data, ups, upsample_factor, axis_offsets):
+    """Two matrix-multiply DFTs on an ``ups x ups`` window (``ptycho.py:163-188``);
+    the contraction is plain linear algebra and stays a ``torch.einsum``."""
+    nb, _, ncol = data.shape
+    dev = data.device
+    freq = torch.fft.fftfreq(ncol, upsample_factor, dtype=torch.float64, device=dev)
+    grid = torch.arange(ups, dtype=torch.float64, device=dev)[None, :]
+
+    def dft_matrix(off):
+        ph = (grid - off[:, None])[:, :, None] * freq
+        return torch.exp(-2j * np.pi * ph.to(torch.complex128))
+
+    tmp = torch.einsum("ijk,ipk->ijp", dft_matrix(axis_offsets[:, 1]), data.to(torch.complex128))
+    return torch.einsum("ijk,ipk->ijp", dft_matrix(axis_offsets[:, 0]), tmp)
+
+
+def _argmax2d(a):
+    flat = a.reshape(a.shape[0], -1).argmax(1)
+    w = a.shape[2]
+    return torch.stack((flat // w, flat % w), dim=1)
+
+
+def register_translation_batch(op, src_image, target_image, upsample_factor=1,
+                               space="real"):
+    """Batched sub-pixel registration by phase cross-correlation
+    (``ptycho.py:190-248``).  ``op`` supplies the 2-D DFT (own HIP FFT)."""
+    if space.lower() == "fourier":
+        src_freq, target_freq = src_image, target_image
+    elif space.lower() == "real":
+        src_freq = op.fft2(src_image.to(torch.complex64))
+        target_freq = op.fft2(target_image.to(torch.complex64))
+    shape = src_freq.shape
+    image_product = src_freq * target_freq.conj()
+    cross = op.fft2(image_product, inverse=True) / float(shape[1] * shape[2])
+    maxima = _argmax2d(torch.abs(cross))
+    mid = [float(np.fix(s / 2)) for s in shape[1:]]
+    shifts = maxima.to(torch.float64)
+    shifts[:, 0] = torch.where(shifts[:, 0] > mid[0], shifts[:, 0] - shape[1], shifts[:, 0])
+    shifts[:, 1] = torch.where(shifts[:, 1] > mid[1], shifts[:, 1] - shape[2], shifts[:, 1])
+    if upsample_factor > 1:
+        shifts = torch.round(shifts * upsample_factor) / upsample_factor
+        region = int(np.ceil(upsample_factor * 1.5))
+        dftshift = float(np.fix(region / 2.0))
+        normalization = shape[1] * shape[2] * upsample_factor ** 2
+        offset = dftshift - shifts * upsample_factor
+        cross = _upsampled_dft_batch(image_product.conj(), region, upsample_factor, offset).conj()
+        cross = cross / normalization
+        maxima = _argmax2d(torch.abs(cross)).to(torch.float64) - dftshift
+        shifts = shifts + maxima / upsample_factor
+    for dim in range(src_freq.ndim):          # reference quirk, ptycho.py:243-245
+        if shape[dim] == 1:
+            shifts[dim] = 0
+    return shifts
+
+
+# ---------------------------------------------------------------------------
+# CG solver (ptycho.py:250-488)
+# ---------------------------------------------------------------------------
+class CGPtychoSolver(PtychoHIP):
+    """Solve the ptychography problem with Dai-Yuan conjugate gradients.
+
+    ``group``: optional ``torch.distributed`` process group; when given, the scan
+    positions (``data``, ``scan``) are this rank's shard, ``psi`` / ``probe`` are
+    replicated, and the object / probe gradients and every global scalar are
+    all-reduced (RCCL over xGMI on MI355X).
+    """
+
+    def __init__(self, nscan, probe_shape, detector_shape, ntheta, nz, n, group=None):
+        super().__init__(nscan, probe_shape, detector_shape, ntheta, nz, n)
+        self.group = group
+        self.history = []      # (iteration, gammapsi, gammaprb, cost) per logged iteration
+        self.verbose = True
+        self.log_every = 32    # the reference prints every 32 iterations (ptycho.py:475)
+
+    # -- distributed glue ----------------------------------------------------
+    def _allreduce(self, t):
+        if self.group is not None:
+            import torch.distributed as dist
+            if torch.is_complex(t):
+                dist.all_reduce(torch.view_as_real(t), group=self.group)
+            else:
+                dist.all_reduce(t, group=self.group)
+        return t
+
+    def _nscan_total(self):
+        if self.group is None:
+            return self.nscan
+        import torch.distributed as dist
+        t = torch.tensor([float(self.nscan)], device=self._device)
+        dist.all_reduce(t, group=self.group)
+        return int(t.item())
+
+    @staticmethod
+    def line_search_sqr(f, p1, p2, p3, step_length=1, step_shrink=0.5):
+        """Backtracking on the closed-form quadratic (``ptycho.py:253-281``)."""
+        assert step_shrink > 0 and step_shrink < 1
+        m = 0
+        fp1 = f(p1)
+        while f(p1 + step_length ** 2 * p2 + step_length * p3) > fp1 + step_shrink * m:
+            if step_length < 1e-32:
+                warnings.warn("Line search failed for conjugate gradient.")
+                return 0
+            step_length *= step_shrink
+        return step_length
+
+    def run(self, data, psi, scan, probe, piter, model="gaussian",
+            recover_prb=False, ortho_prb=False):
+        """Conjugate gradients for ptychography (``ptycho.py:283-488``).
+
+        ``probe`` and ``scan`` are updated in place, like in the reference.
+        """
+        assert probe.ndim == 4, "probe needs 4 dimensions, not %d" % probe.ndim
+        nmodes = probe.shape[1]
+        nscan_total = self._nscan_total()
+
+        def minf(fpsi):
+            if model == "gaussian":
+                f = torch.sum((torch.sqrt(torch.abs(fpsi)) - torch.sqrt(data)) ** 2)
+            elif model == "poisson":
+                f = torch.sum(torch.abs(fpsi) - data * torch.log(torch.abs(fpsi) + 1e-32))
+            return self._allreduce(f)
+
+        def intensity(obj):
+            acc = torch.zeros_like(data)
+            for k in range(nmodes):
+                acc += torch.abs(self.fwd(obj, scan, probe[:, k])) ** 2
+            return acc
+
+        dprb = dpsi = gradprb0 = gradpsi0 = 0
+        if self.verbose:
+            print("# congujate gradient parameters\n"
+                  "iteration, step size object, step size probe, function min")
+        gammaprb = 0
+        for i in range(piter):
+            # 1) object retrieval subproblem with fixed probes -- :325-405
+            absfpsi = intensity(psi)
+            ab = torch.stack((torch.sum(torch.sqrt(absfpsi * data)), torch.sum(absfpsi)))
+            self._allreduce(ab)
+            a, b = ab[0], ab[1]
+            probe *= (a / b)
+            absfpsi *= (a / b) ** 2
+            gradpsi = torch.zeros((self.ptheta, self.nz, self.n), dtype=torch.complex64,
+                                  device=data.device)
+            if model == "gaussian":
+                for k in range(nmodes):
+                    fpsi = self.fwd(psi, scan, probe[:, k]) * (b / a)
+                    gradpsi += self.adj(
+                        fpsi - torch.sqrt(data) * fpsi / (torch.sqrt(absfpsi) + 1e-32),
+                        scan, probe[:, k]) / (torch.max(torch.abs(probe[:, k])) ** 2)
+            elif model == "poisson":
+                for k in range(nmodes):
+                    gradpsi += self.adj(
+                        fpsi - data * fpsi / (absfpsi + 1e-32),    # noqa: F821 (reference bug kept)
+                        scan, probe[:, k]) / (torch.max(torch.abs(probe[:, k])) ** 2)
+            self._allreduce(gradpsi)
+            # Dai-Yuan direction
+            if i == 0:
+                dpsi = -gradpsi
+            else:
+                dpsi = -gradpsi + (
+                    torch.linalg.norm(gradpsi) ** 2
+                    / (torch.sum(torch.conj(dpsi) * (gradpsi - gradpsi0))) * dpsi)
+            gradpsi0 = gradpsi
+            p1, p2, p3 = torch.zeros_like(data), torch.zeros_like(data), torch.zeros_like(data)
+            for k in range(nmodes):
+                tmp1 = self.fwd(psi, scan, probe[:, k])
+                tmp2 = self.fwd(dpsi, scan, probe[:, k])
+                p1 += torch.abs(tmp1) ** 2
+                p2 += torch.abs(tmp2) ** 2
+                p3 += 2 * (tmp1.real * tmp2.real + tmp1.imag * tmp2.imag)
+            gammapsi = 0.5 * self.line_search_sqr(minf, p1, p2, p3)
+
+            # position correction -- :398-403
+            if i > 0:
+                ones = probe[:, 0] * 0 + 1
+                tmp1 = self.fwd(psi, scan, ones)[0]
+                tmp2 = self.fwd(psi + gammapsi * dpsi, scan, ones)[0]
+                shifts = register_translation_batch(self, tmp1, tmp2, upsample_factor=100,
+                                                    space="fourier")
+                scan[0, :] += shifts.to(scan.dtype)
+            psi = psi + gammapsi * dpsi
+
+            if recover_prb:                     # :409-465
+                if i == 0:
+                    gradprb = probe * 0
+                    gradprb0 = probe * 0
+                    dprb = probe * 0
+                for m in range(nmodes):
+                    fprb = self.fwd(psi, scan, probe[:, m])
+                    absfprb = intensity(psi)
+                    if model == "gaussian":
+                        g = self.adj_probe(
+                            fprb - torch.sqrt(data) * fprb / (torch.sqrt(absfprb) + 1e-32),
+                            scan, psi)
+                        self._allreduce(g)
+                        gradprb[:, m] = g / torch.max(torch.abs(psi)) ** 2 / nscan_total * nmodes
+                    elif model == "poisson":
+                        g = self.adj_probe(fprb - data * fprb / (absfprb + 1e-32), scan, psi)
+                        self._allreduce(g)
+                        gradprb[:, m] = g / torch.max(torch.abs(psi)) ** 2 / nscan_total
+                    if i == 0:
+                        dprb[:, m] = -gradprb[:, m]
+                    else:
+                        dprb[:, m] = -gradprb[:, m] + (
+                            torch.linalg.norm(gradprb[:, m]) ** 2
+                            / (torch.sum(torch.conj(dprb[:, m]) * (gradprb[:, m] - gradprb0[:, m])))
+                            * dprb[:, m])
+                    gradprb0[:, m] = gradprb[:, m]
+                    p1 = intensity(psi)
+                    tmp1 = self.fwd(psi, scan, probe[:, m])
+                    tmp2 = self.fwd(psi, scan, dprb[:, m])
+                    p2 = torch.abs(tmp2) ** 2
+                    p3 = 2 * (tmp1.real * tmp2.real + tmp1.imag * tmp2.imag)
+                    gammaprb = 0.5 * self.line_search_sqr(minf, p1, p2, p3, step_length=1)
+                    probe[:, m] = probe[:, m] + gammaprb * dprb[:, m]
+
+            # check convergence -- :475-482 (cost of the start-of-iteration intensity)
+            if i % self.log_every == 0:
+                cost = float(minf(absfpsi))
+                self.history.append((i, float(gammapsi), float(gammaprb), cost))
+                if self.verbose:
+                    print("%4d, %.3e, %.3e, %.7e" % self.history[-1])
+        return {"psi": psi, "probe": probe}

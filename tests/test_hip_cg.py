@@ -1,0 +1,79 @@
+"""CG loop on the GPU against the NumPy oracle loop (same seeded inputs)."""
+import numpy as np
+import pytest
+
+from oracle import cg_oracle as cg
+from libtike.hipfft import synthetic as syn
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pt():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import libtike.hipfft as pt
+    return pt
+
+
+def setup(nmodes=1, ndet=32, seed=7):
+    p = syn.make_problem(6, 6, 6, ndet, ndet, seed=seed)
+    probe = syn.hermite_modes(ndet, nmodes) if nmodes > 1 else p["probe"][:, None].copy()
+    ora = cg.OracleSolver(p["nscan"], ndet, ndet, 1, p["nz"], p["n"])
+    data = np.zeros((1, p["nscan"], ndet, ndet), np.float32)
+    for k in range(probe.shape[1]):
+        data += np.abs(ora.fwd(p["psi"], p["scan"], probe[:, k])) ** 2
+    return p, probe.astype(np.complex64), ora, data
+
+
+@pytest.mark.parametrize("nmodes,recover", [(1, False), (1, True), (2, True)])
+def test_cg_tracks_the_oracle(pt, nmodes, recover):
+    import torch
+    p, probe, ora, data = setup(nmodes)
+    piter = 5
+    start = probe.copy().swapaxes(2, 3) if recover else probe.copy()
+    want = ora.run(data.copy(), np.ones_like(p["psi"]), p["scan"].copy(), start.copy(),
+                   piter=piter, recover_prb=recover)
+    with pt.CGPtychoSolver(p["nscan"], probe.shape[-1], probe.shape[-1], 1, p["nz"], p["n"]) as slv:
+        slv.verbose = False
+        slv.log_every = 1
+        got = slv.run_batch(data.copy(), np.ones_like(p["psi"]), p["scan"].copy(), start.copy(),
+                            piter=piter, recover_prb=recover)
+        hist = list(slv.history)
+    # same cost trajectory (start-of-iteration cost, float32 reductions)
+    for (i, gpsi, gprb, cost), (io, gpsi_o, gprb_o, cost_o) in zip(hist, ora.history):
+        assert i == io
+        assert abs(cost - cost_o) <= 2e-3 * abs(cost_o), (i, cost, cost_o)
+        assert gpsi == gpsi_o and gprb == gprb_o, (i, gpsi, gpsi_o, gprb, gprb_o)
+    d = np.abs(got["psi"] - want["psi"]).max() / np.abs(want["psi"]).max()
+    assert d < 2e-3, d
+    dp = np.abs(got["probe"] - want["probe"]).max() / np.abs(want["probe"]).max()
+    assert dp < 2e-3, dp
+
+
+def test_cg_gradient_vanishes_at_truth(pt):
+    p, probe, ora, data = setup()
+    with pt.CGPtychoSolver(p["nscan"], 32, 32, 1, p["nz"], p["n"]) as slv:
+        slv.verbose = False
+        got = slv.run_batch(data, p["psi"].copy(), p["scan"].copy(), probe.copy(), piter=1)
+    assert np.abs(got["psi"] - p["psi"]).max() < 1e-4
+
+
+def test_registration_recovers_known_shift(pt):
+    import torch
+    from libtike.hipfft.ptycho import register_translation_batch
+    rng = np.random.default_rng(0)
+    img = rng.standard_normal((3, 32, 32))
+    f = np.fft.fft2(img)
+    ky = np.fft.fftfreq(32)[:, None]
+    kx = np.fft.fftfreq(32)[None, :]
+    true = np.array([[1.25, -2.5], [0.0, 0.37], [-3.0, 4.11]])
+    moved = np.stack([f[i] * np.exp(-2j * np.pi * (ky * true[i, 0] + kx * true[i, 1])) for i in range(3)])
+    want = cg.register_translation_batch(f.astype(np.complex64), moved.astype(np.complex64), 100, "fourier")
+    with pt.PtychoCuFFT(3, 32, 32, 1, 64, 64) as slv:
+        got = register_translation_batch(slv, torch.as_tensor(f.astype(np.complex64), device="cuda"),
+                                         torch.as_tensor(moved.astype(np.complex64), device="cuda"),
+                                         100, "fourier").cpu().numpy()
+    np.testing.assert_allclose(got, -true, atol=0.011)
+    np.testing.assert_allclose(got, want, atol=0.011)

@@ -1,0 +1,211 @@
+"""Parity of the HIP operators (through the C ABI, via ``libtike.hipfft``) with the
+CPU oracle.  Everything here needs a real MI355X: ``pytest -m gpu``.
+
+Tolerances (float32 arithmetic on the device, oracle evaluated in float64):
+``REL_MAX`` bounds max|got-want| / max|want|, ``REL_L2`` bounds the relative L2
+error.  The adjoint identity is held to 1e-5 (BASELINE.json), accumulated in
+float64.
+"""
+import numpy as np
+import pytest
+
+from oracle import ptycho_oracle as op
+from libtike.hipfft import synthetic as syn
+
+pytestmark = pytest.mark.gpu
+
+REL_MAX = 2e-5
+REL_L2 = 3e-6
+
+
+@pytest.fixture(scope="module")
+def pt():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import libtike.hipfft as pt
+    return pt
+
+
+def dev(x):
+    import torch
+    return torch.as_tensor(np.ascontiguousarray(x), device="cuda")
+
+
+def host(x):
+    return x.detach().cpu().numpy()
+
+
+def err(got, want):
+    d = np.abs(got.astype(np.complex128) - want)
+    return d.max() / np.abs(want).max(), np.sqrt((d ** 2).sum() / (np.abs(want) ** 2).sum())
+
+
+def vdot(a, b):
+    return np.vdot(b.astype(np.complex128), a.astype(np.complex128))
+
+
+def problem(ndet, nprb, ny, nx, step, ntheta=1, seed=11, hard=True):
+    p = syn.make_problem(ny, nx, step, nprb, ndet, ntheta=ntheta, seed=seed)
+    rng = np.random.default_rng(seed + 1)
+    p["probe"] = (p["probe"] * np.exp(2j * np.pi * rng.random(p["probe"].shape))).astype(np.complex64)
+    if hard and p["nscan"] >= 4:
+        p["scan"][0, 1] = [-1.5, 2.25]                       # skipped (kernels.cu:39)
+        p["scan"][0, 2] = [-0.25, 1.5]                       # trunc -> -0.0, not skipped
+        p["scan"][-1, 3] = [p["nz"] - nprb / 2, 3.75]        # hangs over the bottom edge
+        p["scan"][0, 0] = [2.0, 5.0]                         # exactly integer
+    return p
+
+
+CASES = [
+    # ndet, nprb, ny, nx, step, ntheta
+    (16, 16, 3, 3, 5, 1),
+    (16, 12, 3, 3, 5, 2),
+    (32, 32, 3, 4, 6, 1),
+    (32, 21, 2, 3, 6, 1),
+    (64, 64, 4, 4, 9, 2),
+    (64, 40, 3, 3, 9, 1),
+    (128, 128, 4, 5, 11, 1),
+    (128, 100, 3, 3, 11, 1),
+    (256, 256, 3, 4, 13, 1),
+    (256, 128, 2, 3, 13, 2),
+    (512, 512, 2, 2, 17, 1),
+    (512, 300, 2, 2, 17, 1),
+    (1024, 1024, 1, 2, 17, 1),
+]
+
+
+@pytest.mark.parametrize("ndet,nprb,ny,nx,step,ntheta", CASES)
+def test_fwd_adj_adjprobe_match_oracle(pt, ndet, nprb, ny, nx, step, ntheta):
+    p = problem(ndet, nprb, ny, nx, step, ntheta)
+    rng = np.random.default_rng(2)
+    with pt.PtychoCuFFT(p["nscan"], nprb, ndet, ntheta, p["nz"], p["n"]) as slv:
+        assert (slv.ptheta, slv.nz, slv.n, slv.nscan, slv.ndet, slv.nprb) == \
+            (ntheta, p["nz"], p["n"], p["nscan"], ndet, nprb)
+        psi, scan, prb = dev(p["psi"]), dev(p["scan"]), dev(p["probe"])
+        g = host(slv.fwd(psi, scan, prb))
+        want = op.fwd(p["psi"], p["scan"], p["probe"], ndet, "double")
+        e = err(g, want)
+        assert e[0] < REL_MAX and e[1] < REL_L2, ("fwd", e)
+        if p["nscan"] >= 4:
+            assert np.all(g[0, 1] == 0)    # skipped position -> exact zeros
+        y = (rng.standard_normal(g.shape) + 1j * rng.standard_normal(g.shape)).astype(np.complex64)
+        got = host(slv.adj(dev(y), scan, prb))
+        want = op.adj(y, p["scan"], p["probe"], p["nz"], p["n"], "double")
+        e = err(got, want)
+        assert e[0] < REL_MAX and e[1] < REL_L2, ("adj", e)
+        got = host(slv.adj_probe(dev(y), scan, psi))
+        want = op.adj_probe(y, p["scan"], p["psi"], nprb, "double")
+        e = err(got, want)
+        assert e[0] < REL_MAX and e[1] < REL_L2, ("adj_probe", e)
+
+
+def test_chunking_does_not_change_results(pt):
+    p = problem(64, 48, 5, 5, 7, 2)
+    with pt.PtychoCuFFT(p["nscan"], 48, 64, 2, p["nz"], p["n"]) as slv:
+        psi, scan, prb = dev(p["psi"]), dev(p["scan"]), dev(p["probe"])
+        g0 = host(slv.fwd(psi, scan, prb))
+        a0 = host(slv.adj(dev(g0), scan, prb))
+        slv.set_chunk(7)                   # ragged chunks crossing the angle boundary
+        g1 = host(slv.fwd(psi, scan, prb))
+        a1 = host(slv.adj(dev(g0), scan, prb))
+        b1 = host(slv.adj_probe(dev(g0), scan, psi))
+        slv.set_chunk(0)
+        b0 = host(slv.adj_probe(dev(g0), scan, psi))
+    np.testing.assert_array_equal(g0, g1)
+    assert err(a1, a0.astype(np.complex128))[0] < 1e-5      # atomics: order differs
+    assert err(b1, b0.astype(np.complex128))[0] < 1e-5
+
+
+def test_fft2_matches_numpy(pt):
+    rng = np.random.default_rng(0)
+    for ndet in (16, 32, 64, 128, 256, 512, 1024):
+        nb = 3
+        x = (rng.standard_normal((nb, ndet, ndet)) + 1j * rng.standard_normal((nb, ndet, ndet))).astype(np.complex64)
+        with pt.PtychoCuFFT(1, ndet, ndet, 1, ndet + 2, ndet + 2) as slv:
+            f = host(slv.fft2(dev(x)))
+            b = host(slv.fft2(dev(x), inverse=True))
+            xd = dev(x)
+            inplace = host(slv.fft2(xd, out=xd))
+        wf = np.fft.fft2(x.astype(np.complex128))
+        wb = np.fft.ifft2(x.astype(np.complex128)) * ndet * ndet
+        assert err(f, wf)[1] < REL_L2 and err(b, wb)[1] < REL_L2, ndet
+        np.testing.assert_array_equal(inplace, f)
+
+
+def test_reference_adjoint_script(pt, model):
+    """/root/reference/tests/test_adjoint.py:15-59 through the *_batch API."""
+    n, nz, nscan, nprb, ndet = 600, 276, 100, 128, 128
+    prb0 = np.zeros([1, 1, nprb, nprb], dtype="complex64")
+    prb0[0] = model["prbamp"] * np.exp(1j * model["prbang"])
+    scan = np.ones([1, nscan, 2], dtype="float32")
+    temp = np.moveaxis(model["coords"], 0, 1)[:nscan]
+    scan[0, :, 0] = temp[:, 1]
+    scan[0, :, 1] = temp[:, 0]
+    psi0 = np.ones([1, nz, n], dtype="complex64")
+    psi0[0] = model["initpsiamp"] * np.exp(1j * model["initpsiang"])
+    with pt.PtychoCuFFT(nscan, nprb, ndet, 1, nz, n) as slv:
+        t1 = slv.fwd_ptycho_batch(psi0, scan, prb0)
+        t2 = slv.adj_ptycho_batch(t1, scan, prb0)
+        t3 = slv.adj_ptycho_batch_prb(t1, scan, psi0)
+    a = np.sum(psi0 * np.conj(t2))
+    b = np.sum(t1 * np.conj(t1))
+    c = np.sum(prb0 * np.conj(t3))
+    assert ((a - b) / a < 1e-3) & ((a - c) / a < 1e-3)       # the reference's PASSED line
+    a, b, c = vdot(psi0, t2), vdot(t1, t1), vdot(prb0[:, 0], t3)
+    assert abs(a - b) / abs(a) < 1e-5 and abs(a - c) / abs(a) < 1e-5
+    want = op.fwd(psi0, scan, prb0[:, 0], ndet, "double")
+    e = err(t1, want)
+    assert e[0] < REL_MAX and e[1] < REL_L2
+
+
+@pytest.mark.parametrize("nprb", [256, 128])
+def test_adjoint_identity_full_size(pt, nprb):
+    """BASELINE.json config 2 geometry: 4096 x (256 x 256), <Ax,y> = <x,A*y> with
+    an independent random y, both adjoints, relative residual < 1e-5."""
+    import torch
+    p = syn.make_problem(64, 64, 8, nprb, 256, seed=1234, nz=768, n=768)
+    with pt.PtychoCuFFT(4096, nprb, 256, 1, 768, 768) as slv:
+        psi, scan, prb = dev(p["psi"]), dev(p["scan"]), dev(p["probe"])
+        gen = torch.Generator(device="cuda").manual_seed(5)
+        y = torch.view_as_complex(torch.randn((1, 4096, 256, 256, 2), generator=gen,
+                                              device="cuda", dtype=torch.float32))
+        Ax = slv.fwd(psi, scan, prb)
+        lhs = torch.sum(Ax.to(torch.complex128) * y.conj().to(torch.complex128))
+        Aty = slv.adj(y, scan, prb)
+        rhs1 = torch.sum(psi.to(torch.complex128) * Aty.conj().to(torch.complex128))
+        Bty = slv.adj_probe(y, scan, psi)
+        rhs2 = torch.sum(prb.to(torch.complex128) * Bty.conj().to(torch.complex128))
+        # Parseval: ||Ax||^2 = ||prb * patch||^2 -- checked on a sample of positions
+        sel = np.arange(0, 4096, 512)
+        q = p["probe"][:, None] * op.patches(p["psi"], p["scan"][:, sel], nprb, "double")
+        got = (torch.abs(Ax[0, sel].to(torch.complex128)) ** 2).sum(dim=(1, 2)).cpu().numpy()
+        want = (np.abs(q[0]) ** 2).sum(axis=(1, 2))
+        lhs, rhs1, rhs2 = complex(lhs), complex(rhs1), complex(rhs2)
+    assert abs(lhs - rhs1) / abs(lhs) < 1e-5
+    assert abs(lhs - rhs2) / abs(lhs) < 1e-5
+    np.testing.assert_allclose(got, want, rtol=1e-5)
+
+
+def test_error_behaviour(pt):
+    import torch
+    from libtike.hipfft import _native as nat
+    with pytest.raises(nat.PtychoHipError):
+        pt.PtychoCuFFT(4, 16, 48, 1, 64, 64)          # ndet not a power of two
+    with pytest.raises(nat.PtychoHipError):
+        pt.PtychoCuFFT(4, 32, 16, 1, 64, 64)          # nprb > ndet
+    slv = pt.PtychoCuFFT(4, 16, 16, 1, 64, 64)
+    psi = torch.ones((1, 64, 64), dtype=torch.complex64, device="cuda")
+    scan = torch.ones((1, 4, 2), dtype=torch.float32, device="cuda")
+    prb = torch.ones((1, 16, 16), dtype=torch.complex64, device="cuda")
+    with pytest.raises(AssertionError):
+        slv.fwd(psi.to(torch.complex128), scan, prb)  # dtype assert, ptycho.py:82-84
+    with pytest.raises(ValueError):
+        slv.fwd(psi[:, :32], scan, prb)               # wrong shape never reaches the kernel
+    slv.fwd(psi, scan, prb)
+    slv.free()
+    slv.free()                                        # idempotent, ptychofft.cu:49-57
+    with pytest.raises(nat.PtychoHipError):
+        slv.fwd(psi, scan, prb)
+    with pytest.raises(NotImplementedError):
+        pt.PtychoCuFFT(4, 16, 16, 1, 64, 64).run(None, None, None, None)
