@@ -20,6 +20,12 @@ def pt():
 def setup(nmodes=1, ndet=32, seed=7):
     p = syn.make_problem(6, 6, 6, ndet, ndet, seed=seed)
     probe = syn.hermite_modes(ndet, nmodes) if nmodes > 1 else p["probe"][:, None].copy()
+    # A smooth Gaussian probe on a flat start object predicts ~zero amplitude on most of the
+    # detector, where the projection f/|f| takes the phase of float32 rounding noise: the CG
+    # trajectory is then not reproducible across FFT implementations (the reference's cuFFT
+    # included).  A random phase screen spreads the model over the whole detector.
+    rng = np.random.default_rng(seed + 100)
+    probe = probe * np.exp(2j * np.pi * rng.random(probe.shape[-2:]))
     ora = cg.OracleSolver(p["nscan"], ndet, ndet, 1, p["nz"], p["n"])
     data = np.zeros((1, p["nscan"], ndet, ndet), np.float32)
     for k in range(probe.shape[1]):
@@ -44,12 +50,12 @@ def test_cg_tracks_the_oracle(pt, nmodes, recover):
     # same cost trajectory (start-of-iteration cost, float32 reductions)
     for (i, gpsi, gprb, cost), (io, gpsi_o, gprb_o, cost_o) in zip(hist, ora.history):
         assert i == io
-        assert abs(cost - cost_o) <= 2e-3 * abs(cost_o), (i, cost, cost_o)
+        assert abs(cost - cost_o) <= 1e-4 * abs(cost_o), (i, cost, cost_o)
         assert gpsi == gpsi_o and gprb == gprb_o, (i, gpsi, gpsi_o, gprb, gprb_o)
     d = np.abs(got["psi"] - want["psi"]).max() / np.abs(want["psi"]).max()
-    assert d < 2e-3, d
+    assert d < 2e-4, d
     dp = np.abs(got["probe"] - want["probe"]).max() / np.abs(want["probe"]).max()
-    assert dp < 2e-3, dp
+    assert dp < 2e-4, dp
 
 
 def test_cg_gradient_vanishes_at_truth(pt):
