@@ -72,14 +72,15 @@ int ptycho_adj(ptycho_handle h, void* f, const void* g, const void* scan,
 int ptycho_fft2(ptycho_handle h, void* dst, const void* src, size_t nbatch,
                 int dir, void* stream);
 
-/* Tuning knobs: name = "chunk" (patterns per launch pair, 0 = default). */
+/* Tuning knobs: "chunk" (positions per launch pair, 0 = default);
+ * "window" (1 = LDS overlap-add object adjoint [default], 0 = direct atomics). */
 int ptycho_set_option(ptycho_handle h, const char* name, long long value);
 
 /* In-library profiler for bench.py: when enabled, every kernel launch is
  * bracketed by HIP events on the caller's stream.  ptycho_profile_read waits for
  * the recorded launches, returns summed milliseconds and launch counts per kernel
  * (index 0 k_cols<FWD>, 1 k_rows<fwd>, 2 k_rows<inv>, 3 k_cols<ADJ_OBJ>,
- * 4 k_cols<ADJ_PRB>, 5 k_cols<PLAIN>; n >= 6) and clears the record.
+ * 4 k_cols<ADJ_PRB>, 5 k_cols<PLAIN>, 6 position sort; n >= 7) and clears the record.
  * No counterpart in the reference (it has no timing code). */
 int ptycho_profile(ptycho_handle h, int enable);
 int ptycho_profile_read(ptycho_handle h, double* ms, long long* launches, int n);

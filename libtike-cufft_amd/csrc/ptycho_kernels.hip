@@ -20,6 +20,9 @@
 // reads it.
 #include <hip/hip_runtime.h>
 
+#include <cstring>
+#include <rocprim/device/device_radix_sort.hpp>
+
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -49,13 +52,14 @@ struct ColCfg {
 };
 
 struct ColArgs {
-    const c32* src;     // FWD: object f; ADJ_*: chunk scratch (tile index p - p_begin); PLAIN: tiles
+    const c32* src;     // FWD: object f; ADJ_*: chunk scratch (tile index k - k_begin); PLAIN: tiles
     c32* dst;           // FWD: farplane g; ADJ_OBJ: object f; ADJ_PRB: probe; PLAIN: tiles
     const c32* aux;     // FWD / ADJ_OBJ: probe; ADJ_PRB: object f
     const float* scan;  // [ptheta][nscan][2]
     const c32* table;   // exp(-2 pi i k / N)
     Geom ge;
-    int p_begin, p_end; // flattened (angle * nscan + position) range of this launch
+    const int* order;   // processing order: position = order[k] (nullptr: identity)
+    int k_begin, k_end; // range of k handled by this launch; ADJ_* read scratch tile k - k_begin
     int ngroups;        // position groups; grid = nstrips * ngroups
     int strip0, nstrips;
 };
@@ -65,6 +69,7 @@ struct RowArgs {
     c32* dst;
     const c32* table;
     long long nrows;
+    const int* tile_index;   // source tile of local tile j is tile_index[j] (nullptr: j); dst is always local
     int xa, xb;   // columns outside [xa, xb) are read as zero
     int wa, wb;   // only columns in [wa, wb) are written
 };
@@ -161,7 +166,8 @@ __global__ __launch_bounds__(ColCfg<N>::NT) void k_cols(const ColArgs a) {
         }
     };
 
-    for (int p = a.p_begin + group; p < a.p_end; p += a.ngroups) {
+    for (int k = a.k_begin + group; k < a.k_end; k += a.ngroups) {
+        const int p = a.order ? a.order[k] : k;
         const int t = p / ge.nscan;
         if (MODE == M_FWD || MODE == M_ADJ_OBJ) {
             if (t != cur_t) {
@@ -199,7 +205,7 @@ __global__ __launch_bounds__(ColCfg<N>::NT) void k_cols(const ColArgs a) {
         if (MODE == M_ADJ_PRB) ft = a.aux + (size_t)t * ge.nz * ge.n;
         const c32* tile_in = nullptr;
         if (MODE == M_PLAIN) tile_in = a.src + (size_t)p * N * N;
-        if (MODE == M_ADJ_OBJ || MODE == M_ADJ_PRB) tile_in = a.src + (size_t)(p - a.p_begin) * N * N;
+        if (MODE == M_ADJ_OBJ || MODE == M_ADJ_PRB) tile_in = a.src + (size_t)(k - a.k_begin) * N * N;
 
         c32 v[E];
         // ---- step 0 input ---------------------------------------------------
@@ -320,7 +326,8 @@ __global__ __launch_bounds__(256) void k_rows(const RowArgs a) {
     for (long long batch = blockIdx.x; batch < nb; batch += gridDim.x) {
         const long long r = batch * B + f;
         const bool ok = r < a.nrows;
-        const c32* srow = a.src + (size_t)r * N;
+        const long long tile = r / N;
+        const c32* srow = a.src + (size_t)((a.tile_index && ok) ? (long long)a.tile_index[tile] : tile) * N * N + (size_t)(r % N) * N;
         c32* drow = a.dst + (size_t)r * N;
         c32 v[E];
         fft.template load<0>(v, j0, [&](int i) { return (ok && i >= a.xa && i < a.xb) ? srow[i] : zero; });
@@ -346,13 +353,197 @@ __global__ __launch_bounds__(256) void k_rows(const RowArgs a) {
 }
 
 // ---------------------------------------------------------------------------
+// Object adjoint with on-chip overlap-add (replaces the 8 atomics per probe pixel
+// of kernels.cu:69-81).  A workgroup owns one strip of C probe columns and a
+// contiguous run of positions in SORTED order (same angle, same BX-pixel column
+// bucket, ascending row).  Consecutive positions of such a run overlap almost
+// completely in the object, so their contributions are summed in an LDS window
+// (H rows x WC columns of the object, rows addressed modulo H) and only rows that
+// have slid out of the window are added to global memory, once.  Correctness does
+// not depend on the order: a position that does not fit the current window
+// flushes it and re-anchors.
+// ---------------------------------------------------------------------------
+constexpr int kBucketPx = 4;   // BX: column bucket of the sort key, and window slack
+
+template <int N>
+struct WinCfg {
+    static constexpr int C = ColCfg<N>::C;
+    static constexpr int WC = C + kBucketPx;   // window columns
+    static constexpr int H = N + 8;            // window rows (>= nprb + 1)
+    static constexpr bool fits = (size_t)(N * C + H * WC) * sizeof(c32) <= 160 * 1024;
+};
+
+template <int N>
+__global__ __launch_bounds__(ColCfg<N>::NT) void k_cols_adjwin(const ColArgs a, const int seglen) {
+    using P = Plan<N>;
+    using F = Fft<P, +1>;
+    constexpr int E = P::E, T = P::T, C = ColCfg<N>::C, NT = ColCfg<N>::NT;
+    constexpr int LAST = P::NSTEP - 1;
+    constexpr int WC = WinCfg<N>::WC, H = WinCfg<N>::H;
+    constexpr int RL = P::radix(LAST), NsL = P::ns(LAST);
+    __shared__ c32 lds[N * C];
+    __shared__ c32 win[H * WC];
+
+    const int tid = threadIdx.x;
+    const int c = tid % C, j0 = tid / C;
+    const int strip = blockIdx.x % a.nstrips, seg = blockIdx.x / a.nstrips;
+    const int x0 = (a.strip0 + strip) * C;
+    const int x = x0 + c;
+    const Geom ge = a.ge;
+    const int ix = x - ge.pad;
+    const bool col_ok = ix >= 0 && ix < ge.nprb;
+    const float cinv = 1.0f / (float)N;
+    const c32 zero = c32{0.0f, 0.0f};
+
+    F fft;
+    fft.init(j0, a.table);
+    for (int o = tid; o < H * WC; o += NT) win[o] = zero;
+
+    c32 pr[E];
+    int cur_t = -1;
+    // window state (uniform across the workgroup)
+    int t_w = -1, X0 = 0, Ybase = 0, Ytop = 0;   // live object rows [Ybase, Ytop), columns [X0, X0+WC)
+
+    auto flush = [&](int ya, int yb) {   // add rows [ya, yb) to the object and clear them
+        if (yb <= ya) return;
+        c32* fo = a.dst + (size_t)t_w * ge.nz * ge.n;
+        const int cnt = (yb - ya) * WC;
+        for (int o = tid; o < cnt; o += NT) {
+            const int Y = ya + o / WC, col = o % WC;
+            const int slot = (Y % H) * WC + col;
+            const c32 v = win[slot];
+            win[slot] = zero;
+            const int X = X0 + col;
+            if ((v.x != 0.0f || v.y != 0.0f) && Y < ge.nz && X >= 0 && X < ge.n) {
+                float* op = reinterpret_cast<float*>(fo + (size_t)Y * ge.n + X);
+                atomicAdd(op, v.x);
+                atomicAdd(op + 1, v.y);
+            }
+        }
+    };
+
+    const int kb = a.k_begin + seg * seglen;
+    const int ke = kb + seglen < a.k_end ? kb + seglen : a.k_end;
+    __syncthreads();
+    for (int k = kb; k < ke; ++k) {
+        const int p = a.order ? a.order[k] : k;
+        const int t = p / ge.nscan;
+        const Pos q = decode_pos(a.scan, p, ge);
+        if (!q.valid) continue;
+        if (t != cur_t) {
+            const c32* prb = a.aux + (size_t)t * ge.nprb * ge.nprb;
+#pragma unroll
+            for (int b = 0; b < E / RL; ++b) {
+                const int j = j0 + b * T;
+#pragma unroll
+                for (int tt = 0; tt < RL; ++tt) {
+                    const int iy = (j / NsL) * NsL * RL + (j % NsL) + tt * NsL - ge.pad;
+                    const bool ok = col_ok && iy >= 0 && iy < ge.nprb;
+                    pr[b * RL + tt] = ok ? prb[(size_t)iy * ge.nprb + ix] * cinv : zero;
+                }
+            }
+            cur_t = t;
+        }
+        // ---- window bookkeeping (all quantities are workgroup-uniform) ----------
+        const int Xa = q.sx + x0 - ge.pad;   // object column of strip column cc = 0
+        const bool fitsw = (t == t_w) && Xa >= X0 && Xa + C < X0 + WC && q.sy >= Ybase;
+        if (!fitsw) {
+            flush(Ybase, Ytop);
+            t_w = t;
+            X0 = (q.sx / kBucketPx) * kBucketPx + x0 - ge.pad;
+            Ybase = q.sy;
+            Ytop = q.sy;
+        } else if (q.sy > Ybase) {
+            flush(Ybase, q.sy < Ytop ? q.sy : Ytop);
+            Ybase = q.sy;
+            if (Ytop < Ybase) Ytop = Ybase;
+        }
+        if (Ytop < q.sy + ge.nprb + 1) Ytop = q.sy + ge.nprb + 1;
+
+        // ---- inverse DFT over y of this strip -------------------------------------
+        const c32* tile_in = a.src + (size_t)(k - a.k_begin) * N * N;
+        c32 v[E];
+        fft.template load<0>(v, j0, [&](int i) { return tile_in[(size_t)i * N + x]; });
+        fft.template compute<0>(v);
+        if (P::NSTEP > 1) {
+            fft.template store<0>(v, j0, [&](int i, c32 val) { lds[i * C + c] = val; });
+            __syncthreads();
+            fft.template load<1>(v, j0, [&](int i) { return lds[i * C + c]; });
+            if (P::NSTEP > 2) {
+                __syncthreads();
+                fft.template compute<1>(v);
+                fft.template store<1>(v, j0, [&](int i, c32 val) { lds[i * C + c] = val; });
+                __syncthreads();
+                fft.template load<2>(v, j0, [&](int i) { return lds[i * C + c]; });
+            }
+            fft.template compute<LAST>(v);
+            __syncthreads();   // all reads of lds done before it becomes the T tile
+        }
+        // ---- T[y][c] = conj(c * prb) * near ------------------------------------------
+#pragma unroll
+        for (int b = 0; b < E / RL; ++b) {
+            const int j = j0 + b * T;
+            const int base = (j / NsL) * NsL * RL + (j % NsL);
+#pragma unroll
+            for (int tt = 0; tt < RL; ++tt) {
+                const c32 val = v[b * RL + brev(tt, ilog2(RL))];
+                const c32 w = pr[b * RL + tt];
+                lds[(base + tt * NsL) * C + c] = c32{w.x * val.x + w.y * val.y, w.x * val.y - w.y * val.x};
+            }
+        }
+        __syncthreads();
+        // ---- 4-tap bilinear combine (kernels.cu:73-80) into the window -----------------
+        {
+            const float wx0 = 1.0f - q.fx, wy0 = 1.0f - q.fy;
+            const float w00 = wx0 * wy0, w01 = q.fx * wy0, w10 = wx0 * q.fy, w11 = q.fx * q.fy;
+            const int colbase = Xa - X0;
+            const int nout = (ge.nprb + 1) * (C + 1);
+            for (int o = tid; o < nout; o += NT) {
+                const int yy = o / (C + 1), cc = o % (C + 1);
+                const int ixo = x0 - ge.pad + cc;      // probe column of tap (.,0)
+                if (ixo < 0 || ixo > ge.nprb) continue;
+                const int y = yy + ge.pad;
+                const bool r0 = yy < ge.nprb, r1 = yy >= 1;
+                const bool c0 = cc < C, c1 = cc >= 1;
+                const c32 t00 = (r0 && c0) ? lds[y * C + cc] : zero;
+                const c32 t01 = (r0 && c1) ? lds[y * C + cc - 1] : zero;
+                const c32 t10 = (r1 && c0) ? lds[(y - 1) * C + cc] : zero;
+                const c32 t11 = (r1 && c1) ? lds[(y - 1) * C + cc - 1] : zero;
+                const c32 s = t00 * w00 + t01 * w01 + t10 * w10 + t11 * w11;
+                const int slot = ((q.sy + yy) % H) * WC + colbase + cc;
+                win[slot] += s;
+            }
+        }
+        __syncthreads();
+    }
+    flush(Ybase, Ytop);
+}
+
+// sort key of one position: angle | column bucket | row; skipped positions last
+__global__ void k_sort_keys(const float* __restrict__ scan, const Geom ge, const int total,
+                            unsigned long long* __restrict__ keys, int* __restrict__ vals) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= total) return;
+    const Pos q = decode_pos(scan, p, ge);
+    unsigned long long key = ~0ull;
+    if (q.valid) {
+        const unsigned long long t = (unsigned long long)(p / ge.nscan);
+        unsigned long long bx = (unsigned long long)(q.sx / kBucketPx), sy = (unsigned long long)q.sy;
+        if (bx > 0x3fffffull) bx = 0x3fffffull;
+        if (sy > 0x3fffffull) sy = 0x3fffffull;
+        key = (t << 44) | (bx << 22) | sy;
+    }
+    keys[p] = key;
+    vals[p] = p;
+}
+
+// ---------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------
 thread_local std::string g_err;
 
 // kernel ids for the in-library profiler (ptycho_profile_read)
-enum { K_COLS_FWD = 0, K_ROWS_FWD = 1, K_ROWS_INV = 2, K_COLS_ADJ_OBJ = 3, K_COLS_ADJ_PRB = 4, K_COLS_PLAIN = 5, K_COUNT = 6 };
-
+enum { K_COLS_FWD = 0, K_ROWS_FWD = 1, K_ROWS_INV = 2, K_COLS_ADJ_OBJ = 3, K_COLS_ADJ_PRB = 4, K_COLS_PLAIN = 5, K_SORT = 6, K_COUNT = 7 };
 
 int fail(int code, const std::string& msg) {
     g_err = msg;
@@ -373,6 +564,14 @@ struct ptycho_handle_s {
     c32* table = nullptr;     // exp(-2 pi i k / ndet)
     c32* scratch = nullptr;   // chunk * ndet^2 complex64
     long long chunk = 0;      // positions per launch pair
+    // position sort (object / probe adjoint)
+    unsigned long long* keys_a = nullptr;
+    unsigned long long* keys_b = nullptr;
+    int* vals_a = nullptr;
+    int* order = nullptr;
+    void* sort_tmp = nullptr;
+    size_t sort_tmp_bytes = 0;
+    int use_window = 1;       // 0: direct-atomics object adjoint (k_cols<ADJ_OBJ>)
     int device = 0;
     int n_cu = 256;
     bool freed = false;
@@ -383,12 +582,29 @@ struct ptycho_handle_s {
 
 namespace {
 
+struct ProfSpan {   // brackets one launch with events when profiling is on
+    ptycho_handle h;
+    hipStream_t st;
+    ptycho_handle_s::Span sp;
+    bool on;
+    ProfSpan(ptycho_handle h_, int kid, hipStream_t st_) : h(h_), st(st_), sp{kid, nullptr, nullptr}, on(h_->profile) {
+        if (on) {
+            on = hipEventCreate(&sp.a) == hipSuccess && hipEventCreate(&sp.b) == hipSuccess &&
+                 hipEventRecord(sp.a, st) == hipSuccess;
+        }
+    }
+    ~ProfSpan() {
+        if (on && hipEventRecord(sp.b, st) == hipSuccess) h->spans.push_back(sp);
+    }
+};
+
 long long default_chunk(const Geom& ge) {
     const char* env = std::getenv("PTYCHO_HIP_CHUNK");
     if (env && std::atoll(env) > 0) return std::atoll(env);
-    // keep one chunk's intermediate (ndet^2 * 8 B per position) around 64 MiB
+    // Large chunks stream best (measured: the row pass runs at ~5-6 TB/s for chunks
+    // >= 256 MiB; small chunks only add launch gaps).  Cap the scratch at 4 GiB.
     const long long per = (long long)ge.ndet * ge.ndet * 8;
-    long long c = (64ll << 20) / per;
+    long long c = (4ll << 30) / per;
     if (c < 16) c = 16;
     return c;
 }
@@ -405,10 +621,12 @@ int alloc_scratch(ptycho_handle h) {
     return PTYCHO_OK;
 }
 
+int sort_positions(ptycho_handle h, const float* scan, hipStream_t st);   // ptycho_sort.hip-style helper below
+
 template <int N, int DIR, int MODE>
 int launch_cols(ptycho_handle h, ColArgs a, hipStream_t st) {
     using CC = ColCfg<N>;
-    const int np = a.p_end - a.p_begin;
+    const int np = a.k_end - a.k_begin;
     if (np <= 0 || a.nstrips <= 0) return PTYCHO_OK;
     int target = h->n_cu * 8;
     int ng = target / a.nstrips;
@@ -416,11 +634,30 @@ int launch_cols(ptycho_handle h, ColArgs a, hipStream_t st) {
     if (ng > np) ng = np;
     a.ngroups = ng;
     constexpr int kid = MODE == M_FWD ? K_COLS_FWD : MODE == M_ADJ_OBJ ? K_COLS_ADJ_OBJ : MODE == M_ADJ_PRB ? K_COLS_ADJ_PRB : K_COLS_PLAIN;
-    ptycho_handle_s::Span sp{kid, nullptr, nullptr};
-    if (h->profile) { HIP_TRY(hipEventCreate(&sp.a)); HIP_TRY(hipEventCreate(&sp.b)); HIP_TRY(hipEventRecord(sp.a, st)); }
-    hipLaunchKernelGGL((k_cols<N, DIR, MODE>), dim3((unsigned)(a.nstrips * ng)), dim3(CC::NT), 0, st, a);
+    {
+        ProfSpan ps(h, kid, st);
+        hipLaunchKernelGGL((k_cols<N, DIR, MODE>), dim3((unsigned)(a.nstrips * ng)), dim3(CC::NT), 0, st, a);
+    }
     HIP_TRY(hipGetLastError());
-    if (h->profile) { HIP_TRY(hipEventRecord(sp.b, st)); h->spans.push_back(sp); }
+    return PTYCHO_OK;
+}
+
+template <int N>
+int launch_adjwin(ptycho_handle h, ColArgs a, hipStream_t st) {
+    using CC = ColCfg<N>;
+    const int np = a.k_end - a.k_begin;
+    if (np <= 0 || a.nstrips <= 0) return PTYCHO_OK;
+    // contiguous runs of the sorted order; about 4 workgroups per CU in total
+    int nseg = (h->n_cu * 4 + a.nstrips - 1) / a.nstrips;
+    if (nseg < 1) nseg = 1;
+    int seglen = (np + nseg - 1) / nseg;
+    if (seglen < 8) seglen = 8;
+    nseg = (np + seglen - 1) / seglen;
+    {
+        ProfSpan ps(h, K_COLS_ADJ_OBJ, st);
+        hipLaunchKernelGGL((k_cols_adjwin<N>), dim3((unsigned)(a.nstrips * nseg)), dim3(CC::NT), 0, st, a, seglen);
+    }
+    HIP_TRY(hipGetLastError());
     return PTYCHO_OK;
 }
 
@@ -430,11 +667,11 @@ int launch_rows(ptycho_handle h, RowArgs a, hipStream_t st) {
     if (a.nrows <= 0) return PTYCHO_OK;
     long long nb = (a.nrows + B - 1) / B;
     long long grid = nb < (long long)h->n_cu * 8 ? nb : (long long)h->n_cu * 8;
-    ptycho_handle_s::Span sp{DIR < 0 ? K_ROWS_FWD : K_ROWS_INV, nullptr, nullptr};
-    if (h->profile) { HIP_TRY(hipEventCreate(&sp.a)); HIP_TRY(hipEventCreate(&sp.b)); HIP_TRY(hipEventRecord(sp.a, st)); }
-    hipLaunchKernelGGL((k_rows<N, DIR>), dim3((unsigned)grid), dim3(256), 0, st, a);
+    {
+        ProfSpan ps(h, DIR < 0 ? K_ROWS_FWD : K_ROWS_INV, st);
+        hipLaunchKernelGGL((k_rows<N, DIR>), dim3((unsigned)grid), dim3(256), 0, st, a);
+    }
     HIP_TRY(hipGetLastError());
-    if (h->profile) { HIP_TRY(hipEventRecord(sp.b, st)); h->spans.push_back(sp); }
     return PTYCHO_OK;
 }
 
@@ -457,11 +694,11 @@ int do_fwd(ptycho_handle h, c32* g, const c32* f, const float* scan, const c32* 
         const long long p1 = p0 + h->chunk < total ? p0 + h->chunk : total;
         ColArgs ca{};
         ca.src = f; ca.dst = g; ca.aux = prb; ca.scan = scan; ca.table = h->table; ca.ge = ge;
-        ca.p_begin = (int)p0; ca.p_end = (int)p1; ca.strip0 = strip0; ca.nstrips = nstrips;
+        ca.order = nullptr; ca.k_begin = (int)p0; ca.k_end = (int)p1; ca.strip0 = strip0; ca.nstrips = nstrips;
         int rc = launch_cols<N, -1, M_FWD>(h, ca, st);
         if (rc) return rc;
         RowArgs ra{};
-        ra.src = g + (size_t)p0 * N * N; ra.dst = g + (size_t)p0 * N * N; ra.table = h->table;
+        ra.src = g + (size_t)p0 * N * N; ra.dst = g + (size_t)p0 * N * N; ra.table = h->table; ra.tile_index = nullptr;
         ra.nrows = (p1 - p0) * N; ra.xa = strip0 * C; ra.xb = (strip0 + nstrips) * C; ra.wa = 0; ra.wb = N;
         rc = launch_rows<N, -1>(h, ra, st);
         if (rc) return rc;
@@ -476,19 +713,28 @@ int do_adj(ptycho_handle h, c32* f, const c32* g, const float* scan, c32* prb, i
     const long long total = (long long)ge.ptheta * ge.nscan;
     int strip0, nstrips;
     strip_range<N>(ge, strip0, nstrips);
-    for (long long p0 = 0; p0 < total; p0 += h->chunk) {
-        const long long p1 = p0 + h->chunk < total ? p0 + h->chunk : total;
+    const bool window = flg == 0 && h->use_window && WinCfg<N>::fits;
+    // positions are visited in sorted order (angle, column bucket, row): neighbours in the
+    // object are neighbours in time, which is what the LDS overlap-add window needs
+    int rc = sort_positions(h, scan, st);
+    if (rc) return rc;
+    for (long long k0 = 0; k0 < total; k0 += h->chunk) {
+        const long long k1 = k0 + h->chunk < total ? k0 + h->chunk : total;
         RowArgs ra{};
-        ra.src = g + (size_t)p0 * N * N; ra.dst = h->scratch; ra.table = h->table;
-        ra.nrows = (p1 - p0) * N; ra.xa = 0; ra.xb = N; ra.wa = strip0 * C; ra.wb = (strip0 + nstrips) * C;
-        int rc = launch_rows<N, +1>(h, ra, st);
+        ra.src = g; ra.dst = h->scratch; ra.table = h->table; ra.tile_index = h->order + k0;
+        ra.nrows = (k1 - k0) * N; ra.xa = 0; ra.xb = N; ra.wa = strip0 * C; ra.wb = (strip0 + nstrips) * C;
+        rc = launch_rows<N, +1>(h, ra, st);
         if (rc) return rc;
         ColArgs ca{};
         ca.src = h->scratch; ca.scan = scan; ca.table = h->table; ca.ge = ge;
-        ca.p_begin = (int)p0; ca.p_end = (int)p1; ca.strip0 = strip0; ca.nstrips = nstrips;
+        ca.order = h->order; ca.k_begin = (int)k0; ca.k_end = (int)k1; ca.strip0 = strip0; ca.nstrips = nstrips;
         if (flg == 0) {
             ca.dst = f; ca.aux = prb;
-            rc = launch_cols<N, +1, M_ADJ_OBJ>(h, ca, st);
+            if (window) {
+                if constexpr (WinCfg<N>::fits) rc = launch_adjwin<N>(h, ca, st);
+            } else {
+                rc = launch_cols<N, +1, M_ADJ_OBJ>(h, ca, st);
+            }
         } else {
             ca.dst = prb; ca.aux = f;
             rc = launch_cols<N, +1, M_ADJ_PRB>(h, ca, st);
@@ -502,7 +748,7 @@ template <int N>
 int do_fft2(ptycho_handle h, c32* dst, const c32* src, long long nbatch, int dir, hipStream_t st) {
     constexpr int C = ColCfg<N>::C;
     RowArgs ra{};
-    ra.src = src; ra.dst = dst; ra.table = h->table; ra.nrows = nbatch * N;
+    ra.src = src; ra.dst = dst; ra.table = h->table; ra.nrows = nbatch * N; ra.tile_index = nullptr;
     ra.xa = 0; ra.xb = N; ra.wa = 0; ra.wb = N;
     int rc = dir < 0 ? launch_rows<N, -1>(h, ra, st) : launch_rows<N, +1>(h, ra, st);
     if (rc) return rc;
@@ -512,7 +758,7 @@ int do_fft2(ptycho_handle h, c32* dst, const c32* src, long long nbatch, int dir
         const long long b1 = b0 + slice < nbatch ? b0 + slice : nbatch;
         ColArgs ca{};
         ca.src = dst + (size_t)b0 * N * N; ca.dst = dst + (size_t)b0 * N * N; ca.table = h->table; ca.ge = h->ge;
-        ca.p_begin = 0; ca.p_end = (int)(b1 - b0); ca.strip0 = 0; ca.nstrips = N / C;
+        ca.order = nullptr; ca.k_begin = 0; ca.k_end = (int)(b1 - b0); ca.strip0 = 0; ca.nstrips = N / C;
         rc = dir < 0 ? launch_cols<N, -1, M_PLAIN>(h, ca, st) : launch_cols<N, +1, M_PLAIN>(h, ca, st);
         if (rc) return rc;
     }
@@ -537,12 +783,48 @@ int check_handle(ptycho_handle h) {
     return PTYCHO_OK;
 }
 
+int sort_positions(ptycho_handle h, const float* scan, hipStream_t st) {
+    const int total = h->ge.ptheta * h->ge.nscan;
+    ProfSpan ps(h, K_SORT, st);
+    hipLaunchKernelGGL(k_sort_keys, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, scan, h->ge, total,
+                       h->keys_a, h->vals_a);
+    HIP_TRY(hipGetLastError());
+    size_t bytes = h->sort_tmp_bytes;
+    HIP_TRY(rocprim::radix_sort_pairs(h->sort_tmp, bytes, h->keys_a, h->keys_b, h->vals_a, h->order,
+                                      (size_t)total, 0u, 64u, st));
+    return PTYCHO_OK;
+}
+
+int alloc_sort(ptycho_handle h) {
+    const size_t total = (size_t)h->ge.ptheta * h->ge.nscan;
+    HIP_TRY(hipMalloc((void**)&h->keys_a, total * sizeof(unsigned long long)));
+    HIP_TRY(hipMalloc((void**)&h->keys_b, total * sizeof(unsigned long long)));
+    HIP_TRY(hipMalloc((void**)&h->vals_a, total * sizeof(int)));
+    HIP_TRY(hipMalloc((void**)&h->order, total * sizeof(int)));
+    size_t bytes = 0;
+    HIP_TRY(rocprim::radix_sort_pairs(nullptr, bytes, h->keys_a, h->keys_b, h->vals_a, h->order, total, 0u, 64u,
+                                      (hipStream_t)0));
+    h->sort_tmp_bytes = bytes ? bytes : 16;
+    HIP_TRY(hipMalloc(&h->sort_tmp, h->sort_tmp_bytes));
+    return PTYCHO_OK;
+}
+
+void release(ptycho_handle h) {
+    void* ptrs[] = {h->table, h->scratch, h->keys_a, h->keys_b, h->vals_a, h->order, h->sort_tmp};
+    for (void* q : ptrs)
+        if (q) (void)hipFree(q);
+    h->table = nullptr; h->scratch = nullptr; h->keys_a = nullptr; h->keys_b = nullptr;
+    h->vals_a = nullptr; h->order = nullptr; h->sort_tmp = nullptr;
+    for (auto& sp : h->spans) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
+    h->spans.clear();
+}
+
 }  // namespace
 
 extern "C" {
 
 const char* ptycho_last_error(void) { return g_err.c_str(); }
-const char* ptycho_version(void) { return "ptychohip 0.1 (gfx950)"; }
+const char* ptycho_version(void) { return "ptychohip 0.2 (gfx950)"; }
 
 int ptycho_create(ptycho_handle* out, size_t ptheta, size_t nz, size_t n, size_t nscan, size_t ndet, size_t nprb) {
     if (!out) return fail(PTYCHO_ERR_ARG, "out is null");
@@ -552,7 +834,7 @@ int ptycho_create(ptycho_handle* out, size_t ptheta, size_t nz, size_t n, size_t
     if (ndet < 16 || ndet > 1024 || (ndet & (ndet - 1)) != 0)
         return fail(PTYCHO_ERR_ARG, "ndet must be a power of two in [16, 1024]");
     if (nprb > ndet) return fail(PTYCHO_ERR_ARG, "nprb must be <= ndet");
-    if (ptheta * nscan > (size_t)0x7fffffff / 2 || nz > 65536 * 4 || n > 65536 * 4)
+    if (ptheta * nscan > (size_t)0x7fffffff / 2 || ptheta > (1u << 19) || nz > 65536 * 4 || n > 65536 * 4)
         return fail(PTYCHO_ERR_ARG, "problem too large for 32-bit position indices");
     ptycho_handle h = new ptycho_handle_s();
     h->ge = Geom{(int)ptheta, (int)nz, (int)n, (int)nscan, (int)ndet, (int)nprb, (int)((ndet - nprb) / 2)};
@@ -572,14 +854,17 @@ int ptycho_create(ptycho_handle* out, size_t ptheta, size_t nz, size_t n, size_t
     e = hipMalloc((void**)&h->table, ndet * sizeof(c32));
     if (e == hipSuccess) e = hipMemcpy(h->table, tab.data(), ndet * sizeof(c32), hipMemcpyHostToDevice);
     if (e != hipSuccess) {
-        if (h->table) (void)hipFree(h->table);
+        release(h);
         delete h;
         return fail(PTYCHO_ERR_HIP, std::string("twiddle table: ") + hipGetErrorString(e));
     }
+    const char* env = std::getenv("PTYCHO_HIP_WINDOW");
+    if (env) h->use_window = std::atoi(env) != 0;
     h->chunk = default_chunk(h->ge);
     int rc = alloc_scratch(h);
+    if (!rc) rc = alloc_sort(h);
     if (rc) {
-        (void)hipFree(h->table);
+        release(h);
         delete h;
         return rc;
     }
@@ -591,10 +876,7 @@ int ptycho_free(ptycho_handle h) {
     if (!h) return fail(PTYCHO_ERR_ARG, "null handle");
     if (!h->freed) {
         h->freed = true;
-        if (h->table) (void)hipFree(h->table);
-        if (h->scratch) (void)hipFree(h->scratch);
-        h->table = nullptr;
-        h->scratch = nullptr;
+        release(h);
     }
     return PTYCHO_OK;
 }
@@ -616,6 +898,7 @@ long long ptycho_get(ptycho_handle h, int which) {
         case 4: return h->ge.ndet;
         case 5: return h->ge.nprb;
         case 100: return h->chunk;
+        case 101: return h->use_window;
         default: return -1;
     }
 }
@@ -628,6 +911,10 @@ int ptycho_set_option(ptycho_handle h, const char* name, long long value) {
         h->chunk = value > 0 ? value : default_chunk(h->ge);
         HIP_TRY(hipDeviceSynchronize());
         return alloc_scratch(h);
+    }
+    if (std::strcmp(name, "window") == 0) {
+        h->use_window = value != 0;
+        return PTYCHO_OK;
     }
     return fail(PTYCHO_ERR_ARG, std::string("unknown option ") + name);
 }
@@ -642,7 +929,7 @@ int ptycho_profile(ptycho_handle h, int enable) {
 int ptycho_profile_read(ptycho_handle h, double* ms, long long* launches, int n) {
     int rc = check_handle(h);
     if (rc) return rc;
-    if (!ms || !launches || n < K_COUNT) return fail(PTYCHO_ERR_ARG, "need arrays of at least 6 entries");
+    if (!ms || !launches || n < K_COUNT) return fail(PTYCHO_ERR_ARG, "need arrays of at least 7 entries");
     for (int i = 0; i < n; ++i) { ms[i] = 0.0; launches[i] = 0; }
     for (auto& sp : h->spans) {
         HIP_TRY(hipEventSynchronize(sp.b));

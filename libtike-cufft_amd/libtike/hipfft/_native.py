@@ -47,7 +47,7 @@ profile = _sig("ptycho_profile", _i, _vp, _i)
 profile_read = _sig("ptycho_profile_read", _i, _vp, ctypes.POINTER(ctypes.c_double),
                     ctypes.POINTER(_ll), _i)
 KERNEL_NAMES = ("k_cols<FWD>", "k_rows<fwd>", "k_rows<inv>", "k_cols<ADJ_OBJ>",
-                "k_cols<ADJ_PRB>", "k_cols<PLAIN>")
+                "k_cols<ADJ_PRB>", "k_cols<PLAIN>", "sort_positions")
 last_error = _sig("ptycho_last_error", ctypes.c_char_p)
 version = _sig("ptycho_version", ctypes.c_char_p)
 

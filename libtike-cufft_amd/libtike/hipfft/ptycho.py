@@ -130,15 +130,20 @@ class PtychoHIP:
         """Positions per launch pair (0 = default, about 64 MiB of farplane)."""
         nat.check(nat.set_option(self._h, b"chunk", int(positions)))
 
+    def set_window(self, on=True):
+        """Object adjoint: LDS overlap-add window (default) or direct atomics."""
+        nat.check(nat.set_option(self._h, b"window", int(bool(on))))
+
     def profile(self, enable=True):
         """Bracket every kernel launch with HIP events (bench.py's live timing)."""
         nat.check(nat.profile(self._h, int(bool(enable))))
 
     def profile_read(self):
         """``{kernel: (total_ms, launches)}`` since the last read; waits for them."""
-        ms = (ctypes.c_double * 6)()
-        cnt = (ctypes.c_longlong * 6)()
-        nat.check(nat.profile_read(self._h, ms, cnt, 6))
+        nk = len(nat.KERNEL_NAMES)
+        ms = (ctypes.c_double * nk)()
+        cnt = (ctypes.c_longlong * nk)()
+        nat.check(nat.profile_read(self._h, ms, cnt, nk))
         return {k: (ms[i], int(cnt[i])) for i, k in enumerate(nat.KERNEL_NAMES) if cnt[i]}
 
     # -- helpers -------------------------------------------------------------

@@ -117,6 +117,32 @@ def test_chunking_does_not_change_results(pt):
     assert err(b1, b0.astype(np.complex128))[0] < 1e-5
 
 
+@pytest.mark.parametrize("ndet,nprb,ntheta", [(64, 64, 2), (128, 100, 1), (256, 256, 1)])
+def test_object_adjoint_any_scan_order(pt, ndet, nprb, ntheta):
+    """The LDS overlap-add window must not depend on the scan being a sorted raster:
+    random positions in random order (with skipped and overhanging ones), window on/off."""
+    rng = np.random.default_rng(9)
+    nscan, nz, n = 150, ndet + 90, ndet + 130
+    scan = np.empty((ntheta, nscan, 2), np.float32)
+    scan[..., 0] = rng.random((ntheta, nscan)) * (nz - nprb - 1)
+    scan[..., 1] = rng.random((ntheta, nscan)) * (n - nprb - 1)
+    scan[0, 5] = [-3.5, 4.0]
+    scan[-1, 7] = [nz - nprb / 3, n - nprb / 2]
+    scan[0, 9:12] = scan[0, 8]                      # repeated position
+    prb = (rng.standard_normal((ntheta, nprb, nprb)) + 1j * rng.standard_normal((ntheta, nprb, nprb))).astype(np.complex64)
+    y = (rng.standard_normal((ntheta, nscan, ndet, ndet)) + 1j * rng.standard_normal((ntheta, nscan, ndet, ndet))).astype(np.complex64)
+    want = op.adj(y, scan, prb, nz, n, "double")
+    with pt.PtychoCuFFT(nscan, nprb, ndet, ntheta, nz, n) as slv:
+        got_w = host(slv.adj(dev(y), dev(scan), dev(prb)))
+        slv.set_chunk(37)
+        got_c = host(slv.adj(dev(y), dev(scan), dev(prb)))
+        slv.set_window(False)
+        got_a = host(slv.adj(dev(y), dev(scan), dev(prb)))
+    for got in (got_w, got_c, got_a):
+        e = err(got, want)
+        assert e[0] < REL_MAX and e[1] < REL_L2, e
+
+
 def test_fft2_matches_numpy(pt):
     rng = np.random.default_rng(0)
     for ndet in (16, 32, 64, 128, 256, 512, 1024):
