@@ -519,6 +519,182 @@ __global__ __launch_bounds__(ColCfg<N>::NT) void k_cols_adjwin(const ColArgs a, 
     flush(Ybase, Ytop);
 }
 
+// ---------------------------------------------------------------------------
+// Forward operator / probe adjoint with the object strip cached in LDS.
+// Same run structure as k_cols_adjwin: a workgroup owns C probe columns and a
+// contiguous run of SORTED positions; the object rows it needs slide by a few
+// pixels from one position to the next, so only the new rows are fetched from
+// global memory (the reference re-reads four taps per probe pixel per position,
+// kernels.cu:97-104 / :84-91).  Out-of-object taps are stored as zeros, so no
+// separate edge path exists.
+//   M_FWD     : v = (c*prb) * bilerp(window)  -> DFT over y -> strip of g
+//   M_ADJ_PRB : IDFT over y of the scratch strip; acc += near * conj(bilerp(window))
+// ---------------------------------------------------------------------------
+template <int N, int MODE>
+__global__ __launch_bounds__(ColCfg<N>::NT) void k_cols_gatherwin(const ColArgs a, const int seglen) {
+    using P = Plan<N>;
+    constexpr int DIR = (MODE == M_FWD) ? -1 : +1;
+    using F = Fft<P, DIR>;
+    constexpr int E = P::E, T = P::T, C = ColCfg<N>::C, NT = ColCfg<N>::NT;
+    constexpr int LAST = P::NSTEP - 1;
+    constexpr int WC = WinCfg<N>::WC, H = WinCfg<N>::H;
+    constexpr int R0 = P::radix(0), RL = P::radix(LAST), NsL = P::ns(LAST);
+    __shared__ c32 lds[N * C];
+    __shared__ c32 win[H * WC];
+
+    const int tid = threadIdx.x;
+    const int c = tid % C, j0 = tid / C;
+    const int strip = blockIdx.x % a.nstrips, seg = blockIdx.x / a.nstrips;
+    const int x0 = (a.strip0 + strip) * C;
+    const int x = x0 + c;
+    const Geom ge = a.ge;
+    const int ix = x - ge.pad;
+    const bool col_ok = ix >= 0 && ix < ge.nprb;
+    const float cinv = 1.0f / (float)N;
+    const c32 zero = c32{0.0f, 0.0f};
+
+    F fft;
+    fft.init(j0, a.table);
+
+    c32 pr[E];   // FWD: c * probe strip (step-0 slot order); ADJ_PRB: accumulators (last-step slot order)
+    int cur_t = -1;
+    int t_w = -1, X0 = 0, Ylo = 0, Yhi = 0;   // cached object rows [Ylo, Yhi), columns [X0, X0+WC)
+
+    auto flush_probe = [&](int t) {
+#pragma unroll
+        for (int b = 0; b < E / RL; ++b) {
+            const int j = j0 + b * T;
+            const int base = (j / NsL) * NsL * RL + (j % NsL);
+#pragma unroll
+            for (int tt = 0; tt < RL; ++tt) {
+                const int iy = base + tt * NsL - ge.pad;
+                if (col_ok && iy >= 0 && iy < ge.nprb) {
+                    float* o = reinterpret_cast<float*>(a.dst + ((size_t)t * ge.nprb + iy) * ge.nprb + ix);
+                    const c32 sacc = pr[b * RL + tt] * cinv;
+                    atomicAdd(o, sacc.x);
+                    atomicAdd(o + 1, sacc.y);
+                }
+            }
+        }
+    };
+
+    const int kb = a.k_begin + seg * seglen;
+    const int ke = kb + seglen < a.k_end ? kb + seglen : a.k_end;
+    for (int k = kb; k < ke; ++k) {
+        const int p = a.order ? a.order[k] : k;
+        const int t = p / ge.nscan;
+        const Pos q = decode_pos(a.scan, p, ge);
+        if (MODE == M_FWD) {
+            if (t != cur_t) {
+                const c32* prb = a.aux + (size_t)t * ge.nprb * ge.nprb;
+#pragma unroll
+                for (int b = 0; b < E / R0; ++b)
+#pragma unroll
+                    for (int tt = 0; tt < R0; ++tt) {
+                        const int iy = j0 + b * T + tt * (N / R0) - ge.pad;
+                        const bool ok = col_ok && iy >= 0 && iy < ge.nprb;
+                        pr[b * R0 + tt] = ok ? prb[(size_t)iy * ge.nprb + ix] * cinv : zero;
+                    }
+                cur_t = t;
+            }
+            if (!q.valid) {   // skipped position: exact zeros, as the memset of ptychofft.cu:69 leaves them
+                c32* tile_out = a.dst + (size_t)p * N * N;
+#pragma unroll
+                for (int s2 = 0; s2 < E; ++s2) tile_out[(size_t)(j0 + s2 * T) * N + x] = zero;
+                continue;
+            }
+        } else {
+            if (!q.valid) continue;
+            if (t != cur_t) {
+                if (cur_t >= 0) flush_probe(cur_t);
+#pragma unroll
+                for (int s2 = 0; s2 < E; ++s2) pr[s2] = zero;
+                cur_t = t;
+            }
+        }
+        // ---- slide / re-anchor the cached object window ----------------------------
+        const c32* ft = (MODE == M_FWD ? a.src : a.aux) + (size_t)t * ge.nz * ge.n;
+        const int Xa = q.sx + x0 - ge.pad;
+        const int Ra = q.sy, Rb = q.sy + ge.nprb + 1;
+        const bool colfit = (t == t_w) && Xa >= X0 && Xa + C < X0 + WC;
+        if (!colfit) {
+            t_w = t;
+            X0 = (q.sx / kBucketPx) * kBucketPx + x0 - ge.pad;
+            Ylo = Ra; Yhi = Ra;
+        } else if (Ra < Ylo || Ra > Yhi) {
+            Ylo = Ra; Yhi = Ra;
+        } else {
+            Ylo = Ra;
+        }
+        if (Rb > Yhi) {
+            const int cnt = (Rb - Yhi) * WC;
+            for (int o = tid; o < cnt; o += NT) {
+                const int Y = Yhi + o / WC, col = o % WC;
+                const int X = X0 + col;
+                const bool inb = Y < ge.nz && X >= 0 && X < ge.n;
+                win[(Y % H) * WC + col] = inb ? ft[(size_t)Y * ge.n + X] : zero;
+            }
+            Yhi = Rb;
+        }
+        __syncthreads();
+        const float wx0 = 1.0f - q.fx, wy0 = 1.0f - q.fy;
+        const int colw = Xa - X0 + c;
+        auto patch = [&](int iy) {   // kernels.cu:97-104, taps from the LDS window
+            const int Y = q.sy + iy;
+            const c32* r0 = win + (Y % H) * WC + colw;
+            const c32* r1 = win + ((Y + 1) % H) * WC + colw;
+            return r0[0] * wx0 * wy0 + r0[1] * q.fx * wy0 + r1[0] * wx0 * q.fy + r1[1] * q.fx * q.fy;
+        };
+
+        c32 v[E];
+        if (MODE == M_FWD) {
+#pragma unroll
+            for (int b = 0; b < E / R0; ++b)
+#pragma unroll
+                for (int tt = 0; tt < R0; ++tt) {
+                    const int iy = j0 + b * T + tt * (N / R0) - ge.pad;
+                    const bool ok = col_ok && iy >= 0 && iy < ge.nprb;
+                    v[b * R0 + tt] = ok ? cmul(pr[b * R0 + tt], patch(iy)) : zero;
+                }
+        } else {
+            const c32* tile_in = a.src + (size_t)(k - a.k_begin) * N * N;
+            fft.template load<0>(v, j0, [&](int i) { return tile_in[(size_t)i * N + x]; });
+        }
+        fft.template compute<0>(v);
+        if (P::NSTEP > 1) {
+            fft.template store<0>(v, j0, [&](int i, c32 val) { lds[i * C + c] = val; });
+            __syncthreads();
+            fft.template load<1>(v, j0, [&](int i) { return lds[i * C + c]; });
+            if (P::NSTEP > 2) {
+                __syncthreads();
+                fft.template compute<1>(v);
+                fft.template store<1>(v, j0, [&](int i, c32 val) { lds[i * C + c] = val; });
+                __syncthreads();
+                fft.template load<2>(v, j0, [&](int i) { return lds[i * C + c]; });
+            }
+            fft.template compute<LAST>(v);
+        }
+        if (MODE == M_FWD) {
+            c32* tile_out = a.dst + (size_t)p * N * N;
+            fft.template store<LAST>(v, j0, [&](int i, c32 val) { tile_out[(size_t)i * N + x] = val; });
+        } else {
+#pragma unroll
+            for (int b = 0; b < E / RL; ++b) {
+                const int j = j0 + b * T;
+                const int base = (j / NsL) * NsL * RL + (j % NsL);
+#pragma unroll
+                for (int tt = 0; tt < RL; ++tt) {
+                    const int iy = base + tt * NsL - ge.pad;
+                    if (col_ok && iy >= 0 && iy < ge.nprb)
+                        pr[b * RL + tt] += cmulc(v[b * RL + brev(tt, ilog2(RL))], patch(iy));
+                }
+            }
+        }
+        __syncthreads();   // window and exchange buffer are rewritten by the next position
+    }
+    if (MODE == M_ADJ_PRB && cur_t >= 0) flush_probe(cur_t);
+}
+
 // sort key of one position: angle | column bucket | row; skipped positions last
 __global__ void k_sort_keys(const float* __restrict__ scan, const Geom ge, const int total,
                             unsigned long long* __restrict__ keys, int* __restrict__ vals) {
@@ -661,6 +837,24 @@ int launch_adjwin(ptycho_handle h, ColArgs a, hipStream_t st) {
     return PTYCHO_OK;
 }
 
+template <int N, int MODE>
+int launch_gatherwin(ptycho_handle h, ColArgs a, hipStream_t st) {
+    using CC = ColCfg<N>;
+    const int np = a.k_end - a.k_begin;
+    if (np <= 0 || a.nstrips <= 0) return PTYCHO_OK;
+    int nseg = (h->n_cu * 4 + a.nstrips - 1) / a.nstrips;
+    if (nseg < 1) nseg = 1;
+    int seglen = (np + nseg - 1) / nseg;
+    if (seglen < 8) seglen = 8;
+    nseg = (np + seglen - 1) / seglen;
+    {
+        ProfSpan ps(h, MODE == M_FWD ? K_COLS_FWD : K_COLS_ADJ_PRB, st);
+        hipLaunchKernelGGL((k_cols_gatherwin<N, MODE>), dim3((unsigned)(a.nstrips * nseg)), dim3(CC::NT), 0, st, a, seglen);
+    }
+    HIP_TRY(hipGetLastError());
+    return PTYCHO_OK;
+}
+
 template <int N, int DIR>
 int launch_rows(ptycho_handle h, RowArgs a, hipStream_t st) {
     constexpr int B = 256 / Plan<N>::T;
@@ -690,20 +884,29 @@ int do_fwd(ptycho_handle h, c32* g, const c32* f, const float* scan, const c32* 
     const long long total = (long long)ge.ptheta * ge.nscan;
     int strip0, nstrips;
     strip_range<N>(ge, strip0, nstrips);
-    for (long long p0 = 0; p0 < total; p0 += h->chunk) {
-        const long long p1 = p0 + h->chunk < total ? p0 + h->chunk : total;
-        ColArgs ca{};
-        ca.src = f; ca.dst = g; ca.aux = prb; ca.scan = scan; ca.table = h->table; ca.ge = ge;
-        ca.order = nullptr; ca.k_begin = (int)p0; ca.k_end = (int)p1; ca.strip0 = strip0; ca.nstrips = nstrips;
-        int rc = launch_cols<N, -1, M_FWD>(h, ca, st);
-        if (rc) return rc;
-        RowArgs ra{};
-        ra.src = g + (size_t)p0 * N * N; ra.dst = g + (size_t)p0 * N * N; ra.table = h->table; ra.tile_index = nullptr;
-        ra.nrows = (p1 - p0) * N; ra.xa = strip0 * C; ra.xb = (strip0 + nstrips) * C; ra.wa = 0; ra.wb = N;
-        rc = launch_rows<N, -1>(h, ra, st);
+    const bool window = h->use_window && WinCfg<N>::fits;
+    int rc = PTYCHO_OK;
+    if (window) {
+        rc = sort_positions(h, scan, st);
         if (rc) return rc;
     }
-    return PTYCHO_OK;
+    // The column pass writes straight into g and the row pass transforms g in place, so the
+    // forward operator needs no scratch and is issued as one launch pair over all positions.
+    ColArgs ca{};
+    ca.src = f; ca.dst = g; ca.aux = prb; ca.scan = scan; ca.table = h->table; ca.ge = ge;
+    ca.k_begin = 0; ca.k_end = (int)total; ca.strip0 = strip0; ca.nstrips = nstrips;
+    if (window) {
+        ca.order = h->order;
+        if constexpr (WinCfg<N>::fits) rc = launch_gatherwin<N, M_FWD>(h, ca, st);
+    } else {
+        ca.order = nullptr;
+        rc = launch_cols<N, -1, M_FWD>(h, ca, st);
+    }
+    if (rc) return rc;
+    RowArgs ra{};
+    ra.src = g; ra.dst = g; ra.table = h->table; ra.tile_index = nullptr;
+    ra.nrows = total * N; ra.xa = strip0 * C; ra.xb = (strip0 + nstrips) * C; ra.wa = 0; ra.wb = N;
+    return launch_rows<N, -1>(h, ra, st);
 }
 
 template <int N>
@@ -737,7 +940,11 @@ int do_adj(ptycho_handle h, c32* f, const c32* g, const float* scan, c32* prb, i
             }
         } else {
             ca.dst = prb; ca.aux = f;
-            rc = launch_cols<N, +1, M_ADJ_PRB>(h, ca, st);
+            if (h->use_window && WinCfg<N>::fits) {
+                if constexpr (WinCfg<N>::fits) rc = launch_gatherwin<N, M_ADJ_PRB>(h, ca, st);
+            } else {
+                rc = launch_cols<N, +1, M_ADJ_PRB>(h, ca, st);
+            }
         }
         if (rc) return rc;
     }

@@ -131,16 +131,23 @@ def test_object_adjoint_any_scan_order(pt, ndet, nprb, ntheta):
     scan[0, 9:12] = scan[0, 8]                      # repeated position
     prb = (rng.standard_normal((ntheta, nprb, nprb)) + 1j * rng.standard_normal((ntheta, nprb, nprb))).astype(np.complex64)
     y = (rng.standard_normal((ntheta, nscan, ndet, ndet)) + 1j * rng.standard_normal((ntheta, nscan, ndet, ndet))).astype(np.complex64)
+    psi = (rng.standard_normal((ntheta, nz, n)) + 1j * rng.standard_normal((ntheta, nz, n))).astype(np.complex64)
     want = op.adj(y, scan, prb, nz, n, "double")
+    want_f = op.fwd(psi, scan, prb, ndet, "double")
+    want_p = op.adj_probe(y, scan, psi, nprb, "double")
     with pt.PtychoCuFFT(nscan, nprb, ndet, ntheta, nz, n) as slv:
-        got_w = host(slv.adj(dev(y), dev(scan), dev(prb)))
-        slv.set_chunk(37)
-        got_c = host(slv.adj(dev(y), dev(scan), dev(prb)))
-        slv.set_window(False)
-        got_a = host(slv.adj(dev(y), dev(scan), dev(prb)))
-    for got in (got_w, got_c, got_a):
-        e = err(got, want)
-        assert e[0] < REL_MAX and e[1] < REL_L2, e
+        res = []
+        for chunk, window in ((0, True), (37, True), (0, False)):
+            slv.set_chunk(chunk)
+            slv.set_window(window)
+            res.append((host(slv.adj(dev(y), dev(scan), dev(prb))),
+                        host(slv.fwd(dev(psi), dev(scan), dev(prb))),
+                        host(slv.adj_probe(dev(y), dev(scan), dev(psi)))))
+    for got, got_f, got_p in res:
+        for gg, ww in ((got, want), (got_f, want_f), (got_p, want_p)):
+            e = err(gg, ww)
+            assert e[0] < REL_MAX and e[1] < REL_L2, e
+        assert np.all(got_f[0, 5] == 0)
 
 
 def test_fft2_matches_numpy(pt):
