@@ -72,6 +72,32 @@ int ptycho_adj(ptycho_handle h, void* f, const void* g, const void* scan,
 int ptycho_fft2(ptycho_handle h, void* dst, const void* src, size_t nbatch,
                 int dir, void* stream);
 
+/* ---- fused CG-stage entry points ("plus fused CG-stage entry points") ----
+ * The elementwise stages of CGPtychoSolver.run (src/libtike/cufft/ptycho.py:325-393) are
+ * fused into the row pass of the DFT so that farplanes are never materialised.  The
+ * handle owns two work buffers ("slots" 0/1, one farplane each, allocated on first use)
+ * that hold column-pass intermediates between calls.  sums/cost/costs and ab are DEVICE
+ * pointers to float64 (ab = {a, b} of ptycho.py:342-343; NULL means scale 1); the
+ * kernels ADD into sums/cost/costs, the caller zeroes them.
+ *   ptycho_cg_fwd_cols   slot <- column pass of fwd(f, scan, prb)            (ptycho.py:332)
+ *   ptycho_cg_stats      sums += { sum sqrt(|g|^2 d), sum |g|^2 }            (ptycho.py:333,342-343)
+ *   ptycho_cg_project    dst  <- IDFT_x( fpsi - sqrt(d) fpsi / (sqrt(I)+1e-32) ), cost += ||sqrt I - sqrt d||^2
+ *                                                                             (ptycho.py:344-353,310)
+ *   ptycho_cg_adj_cols   column pass of adj from a slot into f (flg 0) / prb (flg 1) (ptycho.py:352,429)
+ *   ptycho_cg_linesearch costs[j] += f(p1 + y_j^2 p2 + y_j p3), y_j = gamma0 2^-j, j < ncand <= 16;
+ *                        costs[ncand] += f(p1); p1,p2,p3 from slot1 (scaled by a/b) and slot2
+ *                                                                             (ptycho.py:383-393,253-281) */
+int ptycho_cg_fwd_cols(ptycho_handle h, int slot, const void* f, const void* scan,
+                       const void* prb, void* stream);
+int ptycho_cg_stats(ptycho_handle h, int slot, const void* data, double* sums, void* stream);
+int ptycho_cg_project(ptycho_handle h, int src_slot, int dst_slot, const void* data,
+                      const double* ab, double* cost, void* stream);
+int ptycho_cg_adj_cols(ptycho_handle h, int slot, void* f, const void* scan, void* prb,
+                       int flg, void* stream);
+int ptycho_cg_linesearch(ptycho_handle h, int slot1, int slot2, const void* data,
+                         const double* ab, double gamma0, int ncand, double* costs,
+                         void* stream);
+
 /* Tuning knobs: "chunk" (positions per launch pair, 0 = default);
  * "window" (1 = LDS overlap-add object adjoint [default], 0 = direct atomics). */
 int ptycho_set_option(ptycho_handle h, const char* name, long long value);
@@ -80,7 +106,8 @@ int ptycho_set_option(ptycho_handle h, const char* name, long long value);
  * bracketed by HIP events on the caller's stream.  ptycho_profile_read waits for
  * the recorded launches, returns summed milliseconds and launch counts per kernel
  * (index 0 k_cols<FWD>, 1 k_rows<fwd>, 2 k_rows<inv>, 3 k_cols<ADJ_OBJ>,
- * 4 k_cols<ADJ_PRB>, 5 k_cols<PLAIN>, 6 position sort; n >= 7) and clears the record.
+ * 4 k_cols<ADJ_PRB>, 5 k_cols<PLAIN>, 6 position sort, 7-9 fused CG row passes; n >= 10)
+ * and clears the record.
  * No counterpart in the reference (it has no timing code). */
 int ptycho_profile(ptycho_handle h, int enable);
 int ptycho_profile_read(ptycho_handle h, double* ms, long long* launches, int n);

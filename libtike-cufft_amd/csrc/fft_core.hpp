@@ -152,6 +152,21 @@ struct Fft {
         }
     }
 
+    // same step in the opposite direction (conjugate twiddles): lets one kernel run a
+    // forward and an inverse transform with a single set of twiddle registers
+    template <int ST>
+    PTY_FN void compute_rev(c32* v) const {
+        constexpr int R = P::radix(ST);
+#pragma unroll
+        for (int b = 0; b < E / R; ++b) {
+            if (ST > 0) {
+#pragma unroll
+                for (int t = 1; t < R; ++t) v[b * R + t] = cmulc(v[b * R + t], tw[(ST > 0 ? ST - 1 : 0) * E + b * R + t]);
+            }
+            fft_reg<R, -DIR>(v + b * R);
+        }
+    }
+
     // dst(out_index, value) for every point of this thread
     template <int ST, class Dst>
     PTY_FN void store(const c32* v, int j0, Dst dst) const {
@@ -163,6 +178,23 @@ struct Fft {
 #pragma unroll
             for (int t = 0; t < R; ++t) dst(base + t * Ns, v[b * R + brev(t, ilog2(R))]);
         }
+    }
+
+    // Natural order of a thread's E points: element m is index j0 + m*T, both for the
+    // outputs of the last step and for the inputs of step 0 (every N/R is a multiple of T).
+    PTY_FN static void to_natural(const c32* v, c32* nat) {   // after compute<LAST>
+        constexpr int R = P::radix(P::NSTEP - 1);
+#pragma unroll
+        for (int b = 0; b < E / R; ++b)
+#pragma unroll
+            for (int t = 0; t < R; ++t) nat[b + t * (E / R)] = v[b * R + brev(t, ilog2(R))];
+    }
+    PTY_FN static void from_natural(const c32* nat, c32* v) {   // before compute<0>
+        constexpr int R = P::radix(0);
+#pragma unroll
+        for (int b = 0; b < E / R; ++b)
+#pragma unroll
+            for (int t = 0; t < R; ++t) v[b * R + t] = nat[b + t * (E / R)];
     }
 
     // index of the point held in slot (b, t) *before* step ST / *after* the last step

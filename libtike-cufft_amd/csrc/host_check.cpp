@@ -48,6 +48,18 @@ static double check_plan() {
     phase(std::integral_constant<int, 0>{});
     if constexpr (P::NSTEP > 1) phase(std::integral_constant<int, 1>{});
     if constexpr (P::NSTEP > 2) phase(std::integral_constant<int, 2>{});
+    // natural-order helpers: element m of thread j0 must be index j0 + m*T
+    for (int j0 = 0; j0 < T; ++j0) {
+        c32 nat[E], back[E];
+        F::to_natural(v[j0].data(), nat);
+        for (int m = 0; m < E; ++m)
+            if (nat[m].x != y[j0 + m * T].x || nat[m].y != y[j0 + m * T].y) { std::printf("to_natural mismatch N=%d\n", N); return 1.0; }
+        F::from_natural(nat, back);
+        c32 chk[E];
+        th[j0].template load<0>(chk, j0, [&](int i) { return y[i]; });
+        for (int m = 0; m < E; ++m)
+            if (back[m].x != chk[m].x || back[m].y != chk[m].y) { std::printf("from_natural mismatch N=%d\n", N); return 1.0; }
+    }
     double err = 0, nrm = 0;
     for (int k = 0; k < N; ++k) {
         std::complex<double> acc = 0;

@@ -59,6 +59,7 @@ struct ColArgs {
     const c32* table;   // exp(-2 pi i k / N)
     Geom ge;
     const int* order;   // processing order: position = order[k] (nullptr: identity)
+    int natural_tiles;  // ADJ_*: 1 = src tile of position p is tile p (CG work buffers); 0 = tile k - k_begin
     int k_begin, k_end; // range of k handled by this launch; ADJ_* read scratch tile k - k_begin
     int ngroups;        // position groups; grid = nstrips * ngroups
     int strip0, nstrips;
@@ -205,7 +206,7 @@ __global__ __launch_bounds__(ColCfg<N>::NT) void k_cols(const ColArgs a) {
         if (MODE == M_ADJ_PRB) ft = a.aux + (size_t)t * ge.nz * ge.n;
         const c32* tile_in = nullptr;
         if (MODE == M_PLAIN) tile_in = a.src + (size_t)p * N * N;
-        if (MODE == M_ADJ_OBJ || MODE == M_ADJ_PRB) tile_in = a.src + (size_t)(k - a.k_begin) * N * N;
+        if (MODE == M_ADJ_OBJ || MODE == M_ADJ_PRB) tile_in = a.src + (size_t)(a.natural_tiles ? p : (k - a.k_begin)) * N * N;
 
         c32 v[E];
         // ---- step 0 input ---------------------------------------------------
@@ -461,7 +462,7 @@ __global__ __launch_bounds__(ColCfg<N>::NT) void k_cols_adjwin(const ColArgs a, 
         if (Ytop < q.sy + ge.nprb + 1) Ytop = q.sy + ge.nprb + 1;
 
         // ---- inverse DFT over y of this strip -------------------------------------
-        const c32* tile_in = a.src + (size_t)(k - a.k_begin) * N * N;
+        const c32* tile_in = a.src + (size_t)(a.natural_tiles ? p : (k - a.k_begin)) * N * N;
         c32 v[E];
         fft.template load<0>(v, j0, [&](int i) { return tile_in[(size_t)i * N + x]; });
         fft.template compute<0>(v);
@@ -657,7 +658,7 @@ __global__ __launch_bounds__(ColCfg<N>::NT) void k_cols_gatherwin(const ColArgs 
                     v[b * R0 + tt] = ok ? cmul(pr[b * R0 + tt], patch(iy)) : zero;
                 }
         } else {
-            const c32* tile_in = a.src + (size_t)(k - a.k_begin) * N * N;
+            const c32* tile_in = a.src + (size_t)(a.natural_tiles ? p : (k - a.k_begin)) * N * N;
             fft.template load<0>(v, j0, [&](int i) { return tile_in[(size_t)i * N + x]; });
         }
         fft.template compute<0>(v);
@@ -714,12 +715,184 @@ __global__ void k_sort_keys(const float* __restrict__ scan, const Geom ge, const
 }
 
 // ---------------------------------------------------------------------------
+// Row pass fused with the elementwise stages of the CG loop
+// (src/libtike/cufft/ptycho.py:325-393 launches each of them as separate CuPy
+// kernels over farplane-sized temporaries).  Input rows are column-pass
+// intermediates (DFT over y done); the farplane exists only in registers.
+//   EP_STATS      I = |g|^2 ; sums += [sum sqrt(I d), sum I]             (ptycho.py:330-343)
+//   EP_PROJECT    fpsi = (g s)(1/s'), I' = I s^2,
+//                 r = fpsi - sqrt(d) fpsi / (sqrt(I') + 1e-32), cost += (sqrt I' - sqrt d)^2,
+//                 out row = IDFT_x(r)                                    (ptycho.py:344-356, 310)
+//   EP_LINESEARCH t1 = s g1, t2 = g2: p1,p2,p3 (ptycho.py:383-391) and the cost
+//                 sum (sqrt|p1 + y^2 p2 + y p3| - sqrt d)^2 for y = gamma0 * 2^-j, j < ncand,
+//                 plus f(p1) -- every trial of line_search_sqr in one pass (ptycho.py:253-281)
+// ---------------------------------------------------------------------------
+enum RowEp { EP_STATS = 1, EP_PROJECT = 2, EP_LINESEARCH = 3 };
+constexpr int kMaxCand = 16;
+
+struct RowFusedArgs {
+    const c32* s1;
+    const c32* s2;
+    c32* out;
+    const float* data;
+    const c32* table;
+    long long nrows;
+    double* sums;        // EP_STATS: [2]; EP_PROJECT: [1] cost; EP_LINESEARCH: [ncand + 1]
+    const double* ab;    // device scalars a, b of ptycho.py:342-343 (nullptr: scale 1)
+    float gamma0;
+    int ncand;
+    int xa, xb;          // columns outside [xa, xb) of the inputs are zero (never written)
+};
+
+template <int N, int EP>
+__global__ __launch_bounds__(256) void k_rows_fused(const RowFusedArgs a) {
+    using P = Plan<N>;
+    using F = Fft<P, -1>;
+    using L = RowLds<N>;
+    constexpr int E = P::E, T = P::T, B = 256 / T;
+    constexpr int LAST = P::NSTEP - 1;
+    constexpr int NACC = EP == EP_STATS ? 2 : (EP == EP_PROJECT ? 1 : kMaxCand + 1);
+    __shared__ c32 lds[P::NSTEP > 1 ? B * L::FS : 1];
+    __shared__ double red[4 * NACC];
+
+    const int tid = threadIdx.x;
+    const int f = tid / T, j0 = tid % T;
+    F fft;
+    fft.init(j0, a.table);
+    const c32 zero = c32{0.0f, 0.0f};
+    float acc[NACC];
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) acc[i] = 0.0f;
+
+    // scale factors of ptycho.py:344-351 in float32, as the reference computes them
+    float s = 1.0f, sinv = 1.0f;
+    if (a.ab) {
+        const float af = (float)a.ab[0], bf = (float)a.ab[1];
+        s = af / bf;
+        sinv = bf / af;
+    }
+
+    // forward DFT over x of one row held as step-0 inputs in v; result in natural order
+    auto fwd_row = [&](c32* v, c32* nat) {
+        fft.template compute<0>(v);
+        if (P::NSTEP > 1) {
+            fft.template store<0>(v, j0, [&](int i, c32 val) { lds[L::at(f, i)] = val; });
+            __syncthreads();
+            fft.template load<1>(v, j0, [&](int i) { return lds[L::at(f, i)]; });
+            if (P::NSTEP > 2) {
+                __syncthreads();
+                fft.template compute<1>(v);
+                fft.template store<1>(v, j0, [&](int i, c32 val) { lds[L::at(f, i)] = val; });
+                __syncthreads();
+                fft.template load<2>(v, j0, [&](int i) { return lds[L::at(f, i)]; });
+            }
+            fft.template compute<LAST>(v);
+            __syncthreads();   // lds free for the next transform
+        }
+        F::to_natural(v, nat);
+    };
+
+    const long long nb = (a.nrows + B - 1) / B;
+    for (long long batch = blockIdx.x; batch < nb; batch += gridDim.x) {
+        const long long r = batch * B + f;
+        const bool ok = r < a.nrows;
+        const size_t rowoff = (size_t)r * N;
+        c32 v[E], g1[E];
+        fft.template load<0>(v, j0, [&](int i) { return (ok && i >= a.xa && i < a.xb) ? a.s1[rowoff + i] : zero; });
+        fwd_row(v, g1);
+        float d[E];
+#pragma unroll
+        for (int m = 0; m < E; ++m) d[m] = ok ? a.data[rowoff + j0 + m * T] : 0.0f;
+
+        if (EP == EP_STATS) {
+#pragma unroll
+            for (int m = 0; m < E; ++m) {
+                const float I = g1[m].x * g1[m].x + g1[m].y * g1[m].y;
+                acc[0] += sqrtf(I * d[m]);
+                acc[1] += I;
+            }
+        } else if (EP == EP_PROJECT) {
+            const float s2 = s * s;
+            c32 rr[E];
+#pragma unroll
+            for (int m = 0; m < E; ++m) {
+                const float I = (g1[m].x * g1[m].x + g1[m].y * g1[m].y) * s2;
+                const c32 fp = (g1[m] * s) * sinv;
+                const float sd = sqrtf(d[m]), sI = sqrtf(I);
+                rr[m] = fp - (fp * sd) / (sI + 1e-32f);
+                const float df = sI - sd;
+                acc[0] += ok ? df * df : 0.0f;
+            }
+            // inverse DFT over x of the projected row, same twiddle registers (conjugated)
+            F::from_natural(rr, v);
+            fft.template compute_rev<0>(v);
+            if (P::NSTEP > 1) {
+                fft.template store<0>(v, j0, [&](int i, c32 val) { lds[L::at(f, i)] = val; });
+                __syncthreads();
+                fft.template load<1>(v, j0, [&](int i) { return lds[L::at(f, i)]; });
+                if (P::NSTEP > 2) {
+                    __syncthreads();
+                    fft.template compute_rev<1>(v);
+                    fft.template store<1>(v, j0, [&](int i, c32 val) { lds[L::at(f, i)] = val; });
+                    __syncthreads();
+                    fft.template load<2>(v, j0, [&](int i) { return lds[L::at(f, i)]; });
+                }
+                fft.template compute_rev<LAST>(v);
+            }
+            fft.template store<LAST>(v, j0, [&](int i, c32 val) {
+                if (ok) a.out[rowoff + i] = val;
+            });
+            if (P::NSTEP > 1) __syncthreads();
+        } else {   // EP_LINESEARCH
+            c32 g2[E];
+            fft.template load<0>(v, j0, [&](int i) { return (ok && i >= a.xa && i < a.xb) ? a.s2[rowoff + i] : zero; });
+            fwd_row(v, g2);
+#pragma unroll
+            for (int m = 0; m < E; ++m) {
+                const c32 t1 = g1[m] * s;
+                const float p1 = t1.x * t1.x + t1.y * t1.y;
+                const float p2 = g2[m].x * g2[m].x + g2[m].y * g2[m].y;
+                const float p3 = 2.0f * (t1.x * g2[m].x + t1.y * g2[m].y);
+                const float sd = sqrtf(d[m]);
+                float df = sqrtf(fabsf(p1)) - sd;
+                acc[kMaxCand] += df * df;
+                float gam = a.gamma0;
+#pragma unroll
+                for (int j = 0; j < kMaxCand; ++j) {
+                    if (j < a.ncand) {
+                        const float xx = p1 + (gam * gam) * p2 + gam * p3;
+                        df = sqrtf(fabsf(xx)) - sd;
+                        acc[j] += df * df;
+                    }
+                    gam *= 0.5f;
+                }
+            }
+        }
+    }
+    // ---- block reduction (float partials -> double), one atomic per value per workgroup
+    const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) {
+        double x = (double)acc[i];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) x += __shfl_down(x, off, 64);
+        if (lane == 0) red[wave * NACC + i] = x;
+    }
+    __syncthreads();
+    if (tid < NACC) {
+        const double x = red[tid] + red[NACC + tid] + red[2 * NACC + tid] + red[3 * NACC + tid];
+        if (EP != EP_LINESEARCH || tid < a.ncand || tid == kMaxCand)
+            atomicAdd(a.sums + (EP == EP_LINESEARCH && tid == kMaxCand ? a.ncand : tid), x);
+    }
+}
+
+// ---------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------
 thread_local std::string g_err;
 
 // kernel ids for the in-library profiler (ptycho_profile_read)
-enum { K_COLS_FWD = 0, K_ROWS_FWD = 1, K_ROWS_INV = 2, K_COLS_ADJ_OBJ = 3, K_COLS_ADJ_PRB = 4, K_COLS_PLAIN = 5, K_SORT = 6, K_COUNT = 7 };
+enum { K_COLS_FWD = 0, K_ROWS_FWD = 1, K_ROWS_INV = 2, K_COLS_ADJ_OBJ = 3, K_COLS_ADJ_PRB = 4, K_COLS_PLAIN = 5, K_SORT = 6, K_ROWS_STATS = 7, K_ROWS_PROJECT = 8, K_ROWS_LINESEARCH = 9, K_COUNT = 10 };
 
 int fail(int code, const std::string& msg) {
     g_err = msg;
@@ -747,6 +920,7 @@ struct ptycho_handle_s {
     int* order = nullptr;
     void* sort_tmp = nullptr;
     size_t sort_tmp_bytes = 0;
+    c32* work[2] = {nullptr, nullptr};   // CG work buffers (column-pass intermediates), all positions
     int use_window = 1;       // 0: direct-atomics object adjoint (k_cols<ADJ_OBJ>)
     int device = 0;
     int n_cu = 256;
@@ -972,6 +1146,91 @@ int do_fft2(ptycho_handle h, c32* dst, const c32* src, long long nbatch, int dir
     return PTYCHO_OK;
 }
 
+
+// ---- CG-stage helpers ----------------------------------------------------------------
+int ensure_work(ptycho_handle h, int slot) {
+    if (slot < 0 || slot > 1) return fail(PTYCHO_ERR_ARG, "work slot must be 0 or 1");
+    if (!h->work[slot]) {
+        const size_t total = (size_t)h->ge.ptheta * h->ge.nscan;
+        HIP_TRY(hipMalloc((void**)&h->work[slot], total * h->ge.ndet * h->ge.ndet * sizeof(c32)));
+    }
+    return PTYCHO_OK;
+}
+
+template <int N>
+int do_cg_fwd_cols(ptycho_handle h, int slot, const c32* f, const float* scan, const c32* prb, hipStream_t st) {
+    const Geom& ge = h->ge;
+    const long long total = (long long)ge.ptheta * ge.nscan;
+    int strip0, nstrips;
+    strip_range<N>(ge, strip0, nstrips);
+    const bool window = h->use_window && WinCfg<N>::fits;
+    int rc = PTYCHO_OK;
+    if (window) {
+        rc = sort_positions(h, scan, st);
+        if (rc) return rc;
+    }
+    ColArgs ca{};
+    ca.src = f; ca.dst = h->work[slot]; ca.aux = prb; ca.scan = scan; ca.table = h->table; ca.ge = ge;
+    ca.k_begin = 0; ca.k_end = (int)total; ca.strip0 = strip0; ca.nstrips = nstrips;
+    if (window) {
+        ca.order = h->order;
+        if constexpr (WinCfg<N>::fits) rc = launch_gatherwin<N, M_FWD>(h, ca, st);
+    } else {
+        ca.order = nullptr;
+        rc = launch_cols<N, -1, M_FWD>(h, ca, st);
+    }
+    return rc;
+}
+
+template <int N>
+int do_cg_adj_cols(ptycho_handle h, int slot, c32* f, const float* scan, c32* prb, int flg, hipStream_t st) {
+    const Geom& ge = h->ge;
+    const long long total = (long long)ge.ptheta * ge.nscan;
+    int strip0, nstrips;
+    strip_range<N>(ge, strip0, nstrips);
+    int rc = sort_positions(h, scan, st);
+    if (rc) return rc;
+    ColArgs ca{};
+    ca.src = h->work[slot]; ca.scan = scan; ca.table = h->table; ca.ge = ge; ca.natural_tiles = 1;
+    ca.order = h->order; ca.k_begin = 0; ca.k_end = (int)total; ca.strip0 = strip0; ca.nstrips = nstrips;
+    const bool window = h->use_window && WinCfg<N>::fits;
+    if (flg == 0) {
+        ca.dst = f; ca.aux = prb;
+        if (window) {
+            if constexpr (WinCfg<N>::fits) rc = launch_adjwin<N>(h, ca, st);
+        } else {
+            rc = launch_cols<N, +1, M_ADJ_OBJ>(h, ca, st);
+        }
+    } else {
+        ca.dst = prb; ca.aux = f;
+        if (window) {
+            if constexpr (WinCfg<N>::fits) rc = launch_gatherwin<N, M_ADJ_PRB>(h, ca, st);
+        } else {
+            rc = launch_cols<N, +1, M_ADJ_PRB>(h, ca, st);
+        }
+    }
+    return rc;
+}
+
+template <int N, int EP>
+int do_cg_rows(ptycho_handle h, RowFusedArgs a, hipStream_t st) {
+    constexpr int C = ColCfg<N>::C;
+    constexpr int B = 256 / Plan<N>::T;
+    int strip0, nstrips;
+    strip_range<N>(h->ge, strip0, nstrips);
+    a.table = h->table;
+    a.nrows = (long long)h->ge.ptheta * h->ge.nscan * N;
+    a.xa = strip0 * C; a.xb = (strip0 + nstrips) * C;
+    long long nb = (a.nrows + B - 1) / B;
+    long long grid = nb < (long long)h->n_cu * 8 ? nb : (long long)h->n_cu * 8;
+    {
+        ProfSpan ps(h, EP == EP_STATS ? K_ROWS_STATS : EP == EP_PROJECT ? K_ROWS_PROJECT : K_ROWS_LINESEARCH, st);
+        hipLaunchKernelGGL((k_rows_fused<N, EP>), dim3((unsigned)grid), dim3(256), 0, st, a);
+    }
+    HIP_TRY(hipGetLastError());
+    return PTYCHO_OK;
+}
+
 #define PTY_DISPATCH(N_, CALL)                                   \
     switch (N_) {                                                \
         case 16: { constexpr int NN = 16; return CALL; }         \
@@ -1017,7 +1276,8 @@ int alloc_sort(ptycho_handle h) {
 }
 
 void release(ptycho_handle h) {
-    void* ptrs[] = {h->table, h->scratch, h->keys_a, h->keys_b, h->vals_a, h->order, h->sort_tmp};
+    void* ptrs[] = {h->table, h->scratch, h->keys_a, h->keys_b, h->vals_a, h->order, h->sort_tmp, h->work[0], h->work[1]};
+    h->work[0] = nullptr; h->work[1] = nullptr;
     for (void* q : ptrs)
         if (q) (void)hipFree(q);
     h->table = nullptr; h->scratch = nullptr; h->keys_a = nullptr; h->keys_b = nullptr;
@@ -1136,7 +1396,7 @@ int ptycho_profile(ptycho_handle h, int enable) {
 int ptycho_profile_read(ptycho_handle h, double* ms, long long* launches, int n) {
     int rc = check_handle(h);
     if (rc) return rc;
-    if (!ms || !launches || n < K_COUNT) return fail(PTYCHO_ERR_ARG, "need arrays of at least 7 entries");
+    if (!ms || !launches || n < K_COUNT) return fail(PTYCHO_ERR_ARG, "need arrays of at least 10 entries");
     for (int i = 0; i < n; ++i) { ms[i] = 0.0; launches[i] = 0; }
     for (auto& sp : h->spans) {
         HIP_TRY(hipEventSynchronize(sp.b));
@@ -1166,6 +1426,66 @@ int ptycho_adj(ptycho_handle h, void* f, const void* g, const void* scan, void* 
     if (flg != 0 && flg != 1) return fail(PTYCHO_ERR_ARG, "flg must be 0 (object) or 1 (probe)");
     hipStream_t st = (hipStream_t)stream;
     PTY_DISPATCH(h->ge.ndet, (do_adj<NN>(h, (c32*)f, (const c32*)g, (const float*)scan, (c32*)prb, flg, st)));
+}
+
+int ptycho_cg_fwd_cols(ptycho_handle h, int slot, const void* f, const void* scan, const void* prb, void* stream) {
+    int rc = check_handle(h);
+    if (rc) return rc;
+    if (!f || !scan || !prb) return fail(PTYCHO_ERR_ARG, "null operand");
+    rc = ensure_work(h, slot);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    PTY_DISPATCH(h->ge.ndet, (do_cg_fwd_cols<NN>(h, slot, (const c32*)f, (const float*)scan, (const c32*)prb, st)));
+}
+
+int ptycho_cg_adj_cols(ptycho_handle h, int slot, void* f, const void* scan, void* prb, int flg, void* stream) {
+    int rc = check_handle(h);
+    if (rc) return rc;
+    if (!f || !scan || !prb) return fail(PTYCHO_ERR_ARG, "null operand");
+    if (flg != 0 && flg != 1) return fail(PTYCHO_ERR_ARG, "flg must be 0 (object) or 1 (probe)");
+    if (slot < 0 || slot > 1 || !h->work[slot]) return fail(PTYCHO_ERR_ARG, "work slot is empty");
+    hipStream_t st = (hipStream_t)stream;
+    PTY_DISPATCH(h->ge.ndet, (do_cg_adj_cols<NN>(h, slot, (c32*)f, (const float*)scan, (c32*)prb, flg, st)));
+}
+
+int ptycho_cg_stats(ptycho_handle h, int slot, const void* data, double* sums, void* stream) {
+    int rc = check_handle(h);
+    if (rc) return rc;
+    if (!data || !sums) return fail(PTYCHO_ERR_ARG, "null operand");
+    if (slot < 0 || slot > 1 || !h->work[slot]) return fail(PTYCHO_ERR_ARG, "work slot is empty");
+    RowFusedArgs a{};
+    a.s1 = h->work[slot]; a.data = (const float*)data; a.sums = sums;
+    hipStream_t st = (hipStream_t)stream;
+    PTY_DISPATCH(h->ge.ndet, (do_cg_rows<NN, EP_STATS>(h, a, st)));
+}
+
+int ptycho_cg_project(ptycho_handle h, int src_slot, int dst_slot, const void* data, const double* ab,
+                      double* cost, void* stream) {
+    int rc = check_handle(h);
+    if (rc) return rc;
+    if (!data || !cost) return fail(PTYCHO_ERR_ARG, "null operand");
+    if (src_slot < 0 || src_slot > 1 || !h->work[src_slot]) return fail(PTYCHO_ERR_ARG, "work slot is empty");
+    rc = ensure_work(h, dst_slot);
+    if (rc) return rc;
+    RowFusedArgs a{};
+    a.s1 = h->work[src_slot]; a.out = h->work[dst_slot]; a.data = (const float*)data; a.sums = cost; a.ab = ab;
+    hipStream_t st = (hipStream_t)stream;
+    PTY_DISPATCH(h->ge.ndet, (do_cg_rows<NN, EP_PROJECT>(h, a, st)));
+}
+
+int ptycho_cg_linesearch(ptycho_handle h, int slot1, int slot2, const void* data, const double* ab, double gamma0,
+                         int ncand, double* costs, void* stream) {
+    int rc = check_handle(h);
+    if (rc) return rc;
+    if (!data || !costs) return fail(PTYCHO_ERR_ARG, "null operand");
+    if (ncand < 1 || ncand > kMaxCand) return fail(PTYCHO_ERR_ARG, "ncand must be in [1, 16]");
+    if (slot1 < 0 || slot1 > 1 || slot2 < 0 || slot2 > 1 || !h->work[slot1] || !h->work[slot2])
+        return fail(PTYCHO_ERR_ARG, "work slot is empty");
+    RowFusedArgs a{};
+    a.s1 = h->work[slot1]; a.s2 = h->work[slot2]; a.data = (const float*)data; a.sums = costs; a.ab = ab;
+    a.gamma0 = (float)gamma0; a.ncand = ncand;
+    hipStream_t st = (hipStream_t)stream;
+    PTY_DISPATCH(h->ge.ndet, (do_cg_rows<NN, EP_LINESEARCH>(h, a, st)));
 }
 
 int ptycho_fft2(ptycho_handle h, void* dst, const void* src, size_t nbatch, int dir, void* stream) {

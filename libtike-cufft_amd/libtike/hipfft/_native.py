@@ -15,6 +15,8 @@ LIB_PATH = os.path.join(_HERE, "libptychohip.so")
 SYMBOLS = ("ptycho_create", "ptycho_free", "ptycho_destroy", "ptycho_get",
            "ptycho_fwd", "ptycho_adj", "ptycho_fft2", "ptycho_set_option",
            "ptycho_profile", "ptycho_profile_read",
+           "ptycho_cg_fwd_cols", "ptycho_cg_stats", "ptycho_cg_project",
+           "ptycho_cg_adj_cols", "ptycho_cg_linesearch",
            "ptycho_last_error", "ptycho_version")
 
 if not os.path.exists(LIB_PATH):
@@ -43,11 +45,17 @@ fwd = _sig("ptycho_fwd", _i, _vp, _vp, _vp, _vp, _vp, _vp)
 adj = _sig("ptycho_adj", _i, _vp, _vp, _vp, _vp, _vp, _i, _vp)
 fft2 = _sig("ptycho_fft2", _i, _vp, _vp, _vp, _sz, _i, _vp)
 set_option = _sig("ptycho_set_option", _i, _vp, ctypes.c_char_p, _ll)
+cg_fwd_cols = _sig("ptycho_cg_fwd_cols", _i, _vp, _i, _vp, _vp, _vp, _vp)
+cg_stats = _sig("ptycho_cg_stats", _i, _vp, _i, _vp, _vp, _vp)
+cg_project = _sig("ptycho_cg_project", _i, _vp, _i, _i, _vp, _vp, _vp, _vp)
+cg_adj_cols = _sig("ptycho_cg_adj_cols", _i, _vp, _i, _vp, _vp, _vp, _i, _vp)
+cg_linesearch = _sig("ptycho_cg_linesearch", _i, _vp, _i, _i, _vp, _vp, ctypes.c_double, _i, _vp, _vp)
 profile = _sig("ptycho_profile", _i, _vp, _i)
 profile_read = _sig("ptycho_profile_read", _i, _vp, ctypes.POINTER(ctypes.c_double),
                     ctypes.POINTER(_ll), _i)
 KERNEL_NAMES = ("k_cols<FWD>", "k_rows<fwd>", "k_rows<inv>", "k_cols<ADJ_OBJ>",
-                "k_cols<ADJ_PRB>", "k_cols<PLAIN>", "sort_positions")
+                "k_cols<ADJ_PRB>", "k_cols<PLAIN>", "sort_positions",
+                "k_rows_fused<STATS>", "k_rows_fused<PROJECT>", "k_rows_fused<LINESEARCH>")
 last_error = _sig("ptycho_last_error", ctypes.c_char_p)
 version = _sig("ptycho_version", ctypes.c_char_p)
 

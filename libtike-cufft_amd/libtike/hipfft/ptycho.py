@@ -257,6 +257,14 @@ def _single_mode(probe):
 PtychoCuFFT = PtychoHIP
 
 
+def _dy_direction(i, grad, grad0, d):
+    """Dai-Yuan direction with the reference's complex beta (ptycho.py:366-372)."""
+    if i == 0:
+        return -grad
+    return -grad + (torch.linalg.norm(grad) ** 2
+                    / (torch.sum(torch.conj(d) * (grad - grad0))) * d)
+
+
 # ---------------------------------------------------------------------------
 # position registration (ptycho.py:163-248)
 # ---------------------------------------------------------------------------
@@ -333,6 +341,7 @@ class CGPtychoSolver(PtychoHIP):
         self.history = []      # (iteration, gammapsi, gammaprb, cost) per logged iteration
         self.verbose = True
         self.log_every = 32    # the reference prints every 32 iterations (ptycho.py:475)
+        self.fused = True      # single-mode gaussian loop through the fused CG-stage kernels
 
     # -- distributed glue ----------------------------------------------------
     def _allreduce(self, t):
@@ -365,6 +374,107 @@ class CGPtychoSolver(PtychoHIP):
             step_length *= step_shrink
         return step_length
 
+
+    # -- fused single-mode gaussian loop -------------------------------------------------
+    def _cg_fwd_cols(self, slot, obj, scan, prb):
+        nat.check(nat.cg_fwd_cols(self._h, slot, _ptr(obj), _ptr(scan), _ptr(prb), _stream()))
+
+    def _fused_line_search(self, data, ab, costs):
+        """All trials of ``line_search_sqr`` (ptycho.py:253-281) for 16 step lengths per
+        pass over the two work buffers; returns the accepted step length (0 on failure)."""
+        gamma0 = 1.0
+        while True:
+            costs.zero_()
+            nat.check(nat.cg_linesearch(self._h, 0, 1, _ptr(data), _ptr(ab) if ab is not None else None,
+                                        gamma0, 16, _ptr(costs), _stream()))
+            self._allreduce(costs)
+            c = costs.to(torch.float32).cpu().numpy()      # the reference compares float32 costs
+            step = gamma0
+            for j in range(16):
+                if not (c[j] > c[16]):
+                    return step
+                if step < 1e-32:
+                    warnings.warn("Line search failed for conjugate gradient.")
+                    return 0
+                step *= 0.5
+            gamma0 = step
+
+    def _run_fused(self, data, psi, scan, probe, piter, recover_prb):
+        """``CGPtychoSolver.run`` (ptycho.py:283-488) for one probe mode and the gaussian
+        model, with every farplane-sized elementwise stage fused into the DFT row pass
+        (C ABI ``ptycho_cg_*``).  Work buffer 0 holds the column pass of fwd(psi), which
+        is shared by the intensity statistics, the gradient projection and the line
+        search (the probe rescale ``a/b`` is linear and applied on the fly)."""
+        dev = data.device
+        data = self._operand(data, torch.float32, (self.ptheta, self.nscan, self.ndet, self.ndet), "data")
+        psi = self._operand(psi, torch.complex64, (self.ptheta, self.nz, self.n), "psi")
+        self._operand(scan, torch.float32, (self.ptheta, self.nscan, 2), "scan")
+        assert probe.dtype == torch.complex64 and probe.is_contiguous()
+        nscan_total = self._nscan_total()
+        sums = torch.zeros(2, dtype=torch.float64, device=dev)
+        cost = torch.zeros(1, dtype=torch.float64, device=dev)
+        costs = torch.zeros(17, dtype=torch.float64, device=dev)
+        dpsi = gradpsi0 = None
+        dprb = gradprb0 = None
+        gammaprb = 0
+        if self.verbose:
+            print("# congujate gradient parameters\n"
+                  "iteration, step size object, step size probe, function min")
+        for i in range(piter):
+            # 1) object step ----------------------------------------------------------
+            self._cg_fwd_cols(0, psi, scan, probe[:, 0])
+            sums.zero_()
+            nat.check(nat.cg_stats(self._h, 0, _ptr(data), _ptr(sums), _stream()))
+            self._allreduce(sums)
+            ab32 = sums.to(torch.float32)
+            probe *= (ab32[0] / ab32[1])                                    # :344
+            cost.zero_()
+            nat.check(nat.cg_project(self._h, 0, 1, _ptr(data), _ptr(sums), _ptr(cost), _stream()))
+            gradpsi = torch.zeros((self.ptheta, self.nz, self.n), dtype=torch.complex64, device=dev)
+            nat.check(nat.cg_adj_cols(self._h, 1, _ptr(gradpsi), _ptr(scan), _ptr(probe[:, 0]), 0, _stream()))
+            gradpsi /= (torch.max(torch.abs(probe[:, 0])) ** 2)
+            self._allreduce(gradpsi)
+            dpsi = _dy_direction(i, gradpsi, gradpsi0, dpsi)
+            gradpsi0 = gradpsi
+            self._cg_fwd_cols(1, dpsi, scan, probe[:, 0])
+            gammapsi = 0.5 * self._fused_line_search(data, sums, costs)
+
+            if i > 0:                                                       # :398-403
+                ones = probe[:, 0] * 0 + 1
+                tmp1 = self.fwd(psi, scan, ones)[0]
+                tmp2 = self.fwd(psi + gammapsi * dpsi, scan, ones)[0]
+                shifts = register_translation_batch(self, tmp1, tmp2, upsample_factor=100,
+                                                    space="fourier")
+                scan[0, :] += shifts.to(scan.dtype)
+                del tmp1, tmp2
+            psi = psi + gammapsi * dpsi
+
+            # 2) probe step ------------------------------------------------------------
+            if recover_prb:
+                if i == 0:
+                    gradprb0 = probe * 0
+                    dprb = probe * 0
+                cost2 = torch.zeros(1, dtype=torch.float64, device=dev)
+                self._cg_fwd_cols(0, psi, scan, probe[:, 0])
+                nat.check(nat.cg_project(self._h, 0, 1, _ptr(data), None, _ptr(cost2), _stream()))
+                g = torch.zeros((self.ptheta, self.nprb, self.nprb), dtype=torch.complex64, device=dev)
+                nat.check(nat.cg_adj_cols(self._h, 1, _ptr(psi), _ptr(scan), _ptr(g), 1, _stream()))
+                self._allreduce(g)
+                gradprb = (g / torch.max(torch.abs(psi)) ** 2 / nscan_total * 1)[:, None]
+                dprb = _dy_direction(i, gradprb, gradprb0, dprb)
+                gradprb0 = gradprb
+                self._cg_fwd_cols(1, psi, scan, dprb[:, 0].contiguous())
+                gammaprb = 0.5 * self._fused_line_search(data, None, costs)
+                probe[:, 0] = probe[:, 0] + gammaprb * dprb[:, 0]
+
+            if i % self.log_every == 0:
+                c = cost.clone()
+                self._allreduce(c)
+                self.history.append((i, float(gammapsi), float(gammaprb), float(c.to(torch.float32))))
+                if self.verbose:
+                    print("%4d, %.3e, %.3e, %.7e" % self.history[-1])
+        return {"psi": psi, "probe": probe}
+
     def run(self, data, psi, scan, probe, piter, model="gaussian",
             recover_prb=False, ortho_prb=False):
         """Conjugate gradients for ptychography (``ptycho.py:283-488``).
@@ -373,6 +483,8 @@ class CGPtychoSolver(PtychoHIP):
         """
         assert probe.ndim == 4, "probe needs 4 dimensions, not %d" % probe.ndim
         nmodes = probe.shape[1]
+        if self.fused and nmodes == 1 and model == "gaussian":
+            return self._run_fused(data, psi, scan, probe, piter, recover_prb)
         nscan_total = self._nscan_total()
 
         def minf(fpsi):
