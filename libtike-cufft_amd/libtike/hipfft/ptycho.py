@@ -269,19 +269,29 @@ def _dy_direction(i, grad, grad0, d):
 # position registration (ptycho.py:163-248)
 # ---------------------------------------------------------------------------
 def _upsampled_dft_batch(data, ups, upsample_factor, axis_offsets):
-    """Two matrix-multiply DFTs on an ``ups x ups`` window (``ptycho.py:163-188``);
-    the contraction is plain linear algebra and stays a ``torch.einsum``."""
-    nb, _, ncol = data.shape
+    """Two matrix-multiply DFTs on an ``ups x ups`` window (``ptycho.py:163-188``).
+
+    The reference builds a ``[nscan, ups, ndet]`` complex128 kernel per axis,
+    ``exp(-2 pi i (j - off_i) f_k)``, and contracts it with ``einsum('ijk,ipk->ijp')``.
+    The kernel factors as ``A[j,k] * B[i,k]`` with ``A = exp(-2 pi i j f_k)`` shared by all
+    patterns and ``B = exp(+2 pi i off_i f_k)`` a per-pattern phase, so each contraction is
+    one dense GEMM with ``A`` after an elementwise phase multiply -- same float64 math,
+    no 2.5 GB kernel tensors.  The contraction itself stays torch linear algebra
+    (SURVEY.md section 2, C7)."""
+    nb, nrow, ncol = data.shape
     dev = data.device
     freq = torch.fft.fftfreq(ncol, upsample_factor, dtype=torch.float64, device=dev)
-    grid = torch.arange(ups, dtype=torch.float64, device=dev)[None, :]
+    j = torch.arange(ups, dtype=torch.float64, device=dev)
+    A = torch.exp(-2j * np.pi * (j[:, None] * freq[None, :]).to(torch.complex128))    # [ups, ncol]
 
-    def dft_matrix(off):
-        ph = (grid - off[:, None])[:, :, None] * freq
-        return torch.exp(-2j * np.pi * ph.to(torch.complex128))
+    def phase(off):                                                                   # [nb, ncol]
+        return torch.exp(2j * np.pi * (off[:, None] * freq[None, :]).to(torch.complex128))
 
-    tmp = torch.einsum("ijk,ipk->ijp", dft_matrix(axis_offsets[:, 1]), data.to(torch.complex128))
-    return torch.einsum("ijk,ipk->ijp", dft_matrix(axis_offsets[:, 0]), tmp)
+    x = data.to(torch.complex128) * phase(axis_offsets[:, 1])[:, None, :]             # [nb, p, k]
+    tmp = torch.matmul(x, A.T)                                                        # [nb, p, j]
+    tmp = tmp.transpose(1, 2)                                                         # [nb, j, p]  (= einsum 'ijk,ipk->ijp')
+    y = tmp * phase(axis_offsets[:, 0])[:, None, :]                                   # second axis: k runs over p
+    return torch.matmul(y, A.T).transpose(1, 2)                                       # [nb, j2, j]
 
 
 def _argmax2d(a):
