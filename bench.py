@@ -76,15 +76,26 @@ def cpu_baseline(args, prob):
 
 def main():
     args = parse()
+    # Libraries (RCCL prints a version banner) must not share stdout with the one JSON line:
+    # route fd 1 to stderr until the result is printed.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
     torch.cuda.set_device(local)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("BENCH_FORCE_DIST") == "1":
+        # one process per GPU; "nccl" is RCCL on ROCm.  BENCH_FORCE_DIST=1 exercises the
+        # collective path with a single rank (used to rehearse the N > 1 code on one GPU).
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if "MASTER_ADDR" not in os.environ:
+            os.environ["MASTER_ADDR"] = "127.0.0.1"
+            os.environ.setdefault("MASTER_PORT", "29517")
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local))
     assert world == args.gpus or world == 1, "launch with torch.distributed.run for --gpus > 1"
     ngpu = world
 
@@ -224,8 +235,10 @@ def main():
     if dist:
         dist.barrier()
         dist.destroy_process_group()
+    sys.stdout.flush()
+    os.dup2(real_stdout, 1)
     if rank == 0:
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":
