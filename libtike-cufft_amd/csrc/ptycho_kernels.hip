@@ -371,7 +371,7 @@ struct WinCfg {
     static constexpr int C = ColCfg<N>::C;
     static constexpr int WC = C + kBucketPx;   // window columns
     static constexpr int H = N + 8;            // window rows (>= nprb + 1)
-    static constexpr bool fits = (size_t)(N * C + H * WC) * sizeof(c32) <= 160 * 1024;
+    static constexpr bool fits = (size_t)((N + 2) * (C + 2) + H * WC) * sizeof(c32) <= 160 * 1024;
 };
 
 template <int N>
@@ -381,8 +381,11 @@ __global__ __launch_bounds__(ColCfg<N>::NT) void k_cols_adjwin(const ColArgs a, 
     constexpr int E = P::E, T = P::T, C = ColCfg<N>::C, NT = ColCfg<N>::NT;
     constexpr int LAST = P::NSTEP - 1;
     constexpr int WC = WinCfg<N>::WC, H = WinCfg<N>::H;
-    constexpr int RL = P::radix(LAST), NsL = P::ns(LAST);
-    __shared__ c32 lds[N * C];
+    // exchange buffer = T tile, stored with a zero border: element (row i, column c) lives at
+    // (i + 1) * CP + (c + 1); the border is written once and never touched again, which makes
+    // the four bilinear taps of the combine unconditional loads.
+    constexpr int CP = C + 2;
+    __shared__ c32 lds[(N + 2) * CP];
     __shared__ c32 win[H * WC];
 
     const int tid = threadIdx.x;
@@ -395,12 +398,14 @@ __global__ __launch_bounds__(ColCfg<N>::NT) void k_cols_adjwin(const ColArgs a, 
     const bool col_ok = ix >= 0 && ix < ge.nprb;
     const float cinv = 1.0f / (float)N;
     const c32 zero = c32{0.0f, 0.0f};
+    auto at = [&](int i) { return (i + 1) * CP + c + 1; };
 
     F fft;
     fft.init(j0, a.table);
     for (int o = tid; o < H * WC; o += NT) win[o] = zero;
+    for (int o = tid; o < (N + 2) * CP; o += NT) lds[o] = zero;
 
-    c32 pr[E];
+    c32 pr[E];   // c * probe strip, natural order (row j0 + m*T); zero on padding
     int cur_t = -1;
     // window state (uniform across the workgroup)
     int t_w = -1, X0 = 0, Ybase = 0, Ytop = 0;   // live object rows [Ybase, Ytop), columns [X0, X0+WC)
@@ -423,100 +428,133 @@ __global__ __launch_bounds__(ColCfg<N>::NT) void k_cols_adjwin(const ColArgs a, 
         }
     };
 
+    // combine mapping: item -> (output column cc in [0, C], group of consecutive output rows)
+    constexpr int NRG = NT / (C + 1) > 0 ? NT / (C + 1) : 1;   // row groups
+    constexpr int NITEM = (C + 1) * NRG;
+    const int rpt = (ge.nprb + 1 + NRG - 1) / NRG;              // output rows per item
+
     const int kb = a.k_begin + seg * seglen;
     const int ke = kb + seglen < a.k_end ? kb + seglen : a.k_end;
+
+    struct St { int p, t; Pos q; bool have; };
+    auto decode = [&](int k) -> St {
+        St st;
+        st.have = k < ke;
+        st.p = 0; st.t = 0; st.q = Pos{0, 0, 0.f, 0.f, false, false};
+        if (!st.have) return st;
+        st.p = a.order ? a.order[k] : k;
+        st.t = st.p / ge.nscan;
+        st.q = decode_pos(a.scan, st.p, ge);
+        return st;
+    };
+    auto tile_of = [&](const St& st, int k) {
+        return a.src + (size_t)(a.natural_tiles ? st.p : (k - a.k_begin)) * N * N;
+    };
+
     __syncthreads();
+    St st = decode(kb);
+    c32 v[E];
+    if (st.have && st.q.valid) {
+        const c32* tile_in = tile_of(st, kb);
+        fft.template load<0>(v, j0, [&](int i) { return tile_in[(size_t)i * N + x]; });
+    }
     for (int k = kb; k < ke; ++k) {
-        const int p = a.order ? a.order[k] : k;
-        const int t = p / ge.nscan;
-        const Pos q = decode_pos(a.scan, p, ge);
-        if (!q.valid) continue;
-        if (t != cur_t) {
-            const c32* prb = a.aux + (size_t)t * ge.nprb * ge.nprb;
-#pragma unroll
-            for (int b = 0; b < E / RL; ++b) {
-                const int j = j0 + b * T;
-#pragma unroll
-                for (int tt = 0; tt < RL; ++tt) {
-                    const int iy = (j / NsL) * NsL * RL + (j % NsL) + tt * NsL - ge.pad;
-                    const bool ok = col_ok && iy >= 0 && iy < ge.nprb;
-                    pr[b * RL + tt] = ok ? prb[(size_t)iy * ge.nprb + ix] * cinv : zero;
-                }
+        St nx = decode(k + 1);
+        if (!st.q.valid) {   // skipped position: nothing to add; fetch the next tile
+            if (nx.have && nx.q.valid) {
+                const c32* tile_in = tile_of(nx, k + 1);
+                fft.template load<0>(v, j0, [&](int i) { return tile_in[(size_t)i * N + x]; });
             }
-            cur_t = t;
+            st = nx;
+            continue;
         }
-        // ---- window bookkeeping (all quantities are workgroup-uniform) ----------
+        const Pos q = st.q;
+        if (st.t != cur_t) {
+            const c32* prb = a.aux + (size_t)st.t * ge.nprb * ge.nprb;
+#pragma unroll
+            for (int m = 0; m < E; ++m) {
+                const int iy = j0 + m * T - ge.pad;
+                const bool ok = col_ok && iy >= 0 && iy < ge.nprb;
+                const c32 w = prb[ok ? ((size_t)iy * ge.nprb + ix) : 0];
+                pr[m] = ok ? w * cinv : zero;
+            }
+            cur_t = st.t;
+        }
+        // ---- inverse DFT over y of this strip (tile already in v) ----------------------
+        fft.template compute<0>(v);
+        if (P::NSTEP > 1) {
+            fft.template store<0>(v, j0, [&](int i, c32 val) { lds[at(i)] = val; });
+            __syncthreads();
+            fft.template load<1>(v, j0, [&](int i) { return lds[at(i)]; });
+            if (P::NSTEP > 2) {
+                __syncthreads();
+                fft.template compute<1>(v);
+                fft.template store<1>(v, j0, [&](int i, c32 val) { lds[at(i)] = val; });
+                __syncthreads();
+                fft.template load<2>(v, j0, [&](int i) { return lds[at(i)]; });
+            }
+            fft.template compute<LAST>(v);
+        }
+        // ---- T[y][c] = conj(c * prb) * near, written over the slots this thread just read ----
+        {
+            c32 nat[E];
+            F::to_natural(v, nat);
+#pragma unroll
+            for (int m = 0; m < E; ++m) {
+                const c32 w = pr[m];
+                lds[at(j0 + m * T)] = c32{w.x * nat[m].x + w.y * nat[m].y, w.x * nat[m].y - w.y * nat[m].x};
+            }
+        }
+        // prefetch the next tile while the combine runs
+        if (nx.have && nx.q.valid) {
+            const c32* tile_in = tile_of(nx, k + 1);
+            fft.template load<0>(v, j0, [&](int i) { return tile_in[(size_t)i * N + x]; });
+        }
+        // ---- window bookkeeping (all quantities are workgroup-uniform) -------------------
         const int Xa = q.sx + x0 - ge.pad;   // object column of strip column cc = 0
-        const bool fitsw = (t == t_w) && Xa >= X0 && Xa + C < X0 + WC && q.sy >= Ybase;
+        const bool fitsw = (st.t == t_w) && Xa >= X0 && Xa + C < X0 + WC && q.sy >= Ybase;
         if (!fitsw) {
+            __syncthreads();
             flush(Ybase, Ytop);
-            t_w = t;
+            t_w = st.t;
             X0 = (q.sx / kBucketPx) * kBucketPx + x0 - ge.pad;
             Ybase = q.sy;
             Ytop = q.sy;
         } else if (q.sy > Ybase) {
-            flush(Ybase, q.sy < Ytop ? q.sy : Ytop);
+            flush(Ybase, q.sy < Ytop ? q.sy : Ytop);   // rows below q.sy: disjoint from this combine
             Ybase = q.sy;
             if (Ytop < Ybase) Ytop = Ybase;
         }
         if (Ytop < q.sy + ge.nprb + 1) Ytop = q.sy + ge.nprb + 1;
-
-        // ---- inverse DFT over y of this strip -------------------------------------
-        const c32* tile_in = a.src + (size_t)(a.natural_tiles ? p : (k - a.k_begin)) * N * N;
-        c32 v[E];
-        fft.template load<0>(v, j0, [&](int i) { return tile_in[(size_t)i * N + x]; });
-        fft.template compute<0>(v);
-        if (P::NSTEP > 1) {
-            fft.template store<0>(v, j0, [&](int i, c32 val) { lds[i * C + c] = val; });
-            __syncthreads();
-            fft.template load<1>(v, j0, [&](int i) { return lds[i * C + c]; });
-            if (P::NSTEP > 2) {
-                __syncthreads();
-                fft.template compute<1>(v);
-                fft.template store<1>(v, j0, [&](int i, c32 val) { lds[i * C + c] = val; });
-                __syncthreads();
-                fft.template load<2>(v, j0, [&](int i) { return lds[i * C + c]; });
-            }
-            fft.template compute<LAST>(v);
-            __syncthreads();   // all reads of lds done before it becomes the T tile
-        }
-        // ---- T[y][c] = conj(c * prb) * near ------------------------------------------
-#pragma unroll
-        for (int b = 0; b < E / RL; ++b) {
-            const int j = j0 + b * T;
-            const int base = (j / NsL) * NsL * RL + (j % NsL);
-#pragma unroll
-            for (int tt = 0; tt < RL; ++tt) {
-                const c32 val = v[b * RL + brev(tt, ilog2(RL))];
-                const c32 w = pr[b * RL + tt];
-                lds[(base + tt * NsL) * C + c] = c32{w.x * val.x + w.y * val.y, w.x * val.y - w.y * val.x};
+        __syncthreads();   // T tile complete (and, after a re-anchor, the window is clean)
+        // ---- 4-tap bilinear combine (kernels.cu:73-80) into the window -------------------
+        for (int item = tid; item < NITEM; item += NT) {
+            const int cc = item % (C + 1), rg = item / (C + 1);
+            const int ixo = x0 - ge.pad + cc;                     // probe column of tap (., 0)
+            if (ixo < 0 || ixo > ge.nprb) continue;
+            const float w00 = (1.0f - q.fx) * (1.0f - q.fy), w01 = q.fx * (1.0f - q.fy);
+            const float w10 = (1.0f - q.fx) * q.fy, w11 = q.fx * q.fy;
+            const int y0 = rg * rpt;
+            int y1 = y0 + rpt;
+            if (y1 > ge.nprb + 1) y1 = ge.nprb + 1;
+            if (y0 >= y1) continue;
+            // padded tile: T[y][cc] at (y + 1) * CP + cc + 1 and T[y][cc - 1] at (y + 1) * CP + cc
+            const c32* tp = lds + (y0 + ge.pad) * CP + cc;        // row y - 1 = yy + pad - 1
+            c32 up0 = tp[1], up1 = tp[0];                         // T[y-1][cc], T[y-1][cc-1]
+            int slot = (q.sy + y0) % H;
+            const int colw = Xa - X0 + cc;
+            for (int yy = y0; yy < y1; ++yy) {
+                tp += CP;
+                const c32 t00 = tp[1], t01 = tp[0];
+                win[slot * WC + colw] += t00 * w00 + t01 * w01 + up0 * w10 + up1 * w11;
+                up0 = t00; up1 = t01;
+                slot = slot + 1 == H ? 0 : slot + 1;
             }
         }
-        __syncthreads();
-        // ---- 4-tap bilinear combine (kernels.cu:73-80) into the window -----------------
-        {
-            const float wx0 = 1.0f - q.fx, wy0 = 1.0f - q.fy;
-            const float w00 = wx0 * wy0, w01 = q.fx * wy0, w10 = wx0 * q.fy, w11 = q.fx * q.fy;
-            const int colbase = Xa - X0;
-            const int nout = (ge.nprb + 1) * (C + 1);
-            for (int o = tid; o < nout; o += NT) {
-                const int yy = o / (C + 1), cc = o % (C + 1);
-                const int ixo = x0 - ge.pad + cc;      // probe column of tap (.,0)
-                if (ixo < 0 || ixo > ge.nprb) continue;
-                const int y = yy + ge.pad;
-                const bool r0 = yy < ge.nprb, r1 = yy >= 1;
-                const bool c0 = cc < C, c1 = cc >= 1;
-                const c32 t00 = (r0 && c0) ? lds[y * C + cc] : zero;
-                const c32 t01 = (r0 && c1) ? lds[y * C + cc - 1] : zero;
-                const c32 t10 = (r1 && c0) ? lds[(y - 1) * C + cc] : zero;
-                const c32 t11 = (r1 && c1) ? lds[(y - 1) * C + cc - 1] : zero;
-                const c32 s = t00 * w00 + t01 * w01 + t10 * w10 + t11 * w11;
-                const int slot = ((q.sy + yy) % H) * WC + colbase + cc;
-                win[slot] += s;
-            }
-        }
-        __syncthreads();
+        __syncthreads();   // combine done: the tile may be overwritten by the next position
+        st = nx;
     }
+    __syncthreads();
     flush(Ybase, Ytop);
 }
 
@@ -527,7 +565,8 @@ __global__ __launch_bounds__(ColCfg<N>::NT) void k_cols_adjwin(const ColArgs a, 
 // pixels from one position to the next, so only the new rows are fetched from
 // global memory (the reference re-reads four taps per probe pixel per position,
 // kernels.cu:97-104 / :84-91).  Out-of-object taps are stored as zeros, so no
-// separate edge path exists.
+// separate edge path exists.  The hot loop is branch free: padding pixels are
+// masked by a zero probe value (window is zero-initialised, so stale rows are finite).
 //   M_FWD     : v = (c*prb) * bilerp(window)  -> DFT over y -> strip of g
 //   M_ADJ_PRB : IDFT over y of the scratch strip; acc += near * conj(bilerp(window))
 // ---------------------------------------------------------------------------
@@ -556,71 +595,45 @@ __global__ __launch_bounds__(ColCfg<N>::NT) void k_cols_gatherwin(const ColArgs 
 
     F fft;
     fft.init(j0, a.table);
+    for (int o = tid; o < H * WC; o += NT) win[o] = zero;
 
-    c32 pr[E];   // FWD: c * probe strip (step-0 slot order); ADJ_PRB: accumulators (last-step slot order)
+    // FWD: c * probe strip in step-0 slot order (zero on padding -> masks the gather);
+    // ADJ_PRB: gradient accumulators in natural order m (row j0 + m*T)
+    c32 pr[E];
     int cur_t = -1;
     int t_w = -1, X0 = 0, Ylo = 0, Yhi = 0;   // cached object rows [Ylo, Yhi), columns [X0, X0+WC)
 
     auto flush_probe = [&](int t) {
 #pragma unroll
-        for (int b = 0; b < E / RL; ++b) {
-            const int j = j0 + b * T;
-            const int base = (j / NsL) * NsL * RL + (j % NsL);
-#pragma unroll
-            for (int tt = 0; tt < RL; ++tt) {
-                const int iy = base + tt * NsL - ge.pad;
-                if (col_ok && iy >= 0 && iy < ge.nprb) {
-                    float* o = reinterpret_cast<float*>(a.dst + ((size_t)t * ge.nprb + iy) * ge.nprb + ix);
-                    const c32 sacc = pr[b * RL + tt] * cinv;
-                    atomicAdd(o, sacc.x);
-                    atomicAdd(o + 1, sacc.y);
-                }
+        for (int m = 0; m < E; ++m) {
+            const int iy = j0 + m * T - ge.pad;
+            if (col_ok && iy >= 0 && iy < ge.nprb) {
+                float* o = reinterpret_cast<float*>(a.dst + ((size_t)t * ge.nprb + iy) * ge.nprb + ix);
+                const c32 sacc = pr[m] * cinv;
+                atomicAdd(o, sacc.x);
+                atomicAdd(o + 1, sacc.y);
             }
         }
     };
 
-    const int kb = a.k_begin + seg * seglen;
-    const int ke = kb + seglen < a.k_end ? kb + seglen : a.k_end;
-    for (int k = kb; k < ke; ++k) {
-        const int p = a.order ? a.order[k] : k;
-        const int t = p / ge.nscan;
-        const Pos q = decode_pos(a.scan, p, ge);
-        if (MODE == M_FWD) {
-            if (t != cur_t) {
-                const c32* prb = a.aux + (size_t)t * ge.nprb * ge.nprb;
-#pragma unroll
-                for (int b = 0; b < E / R0; ++b)
-#pragma unroll
-                    for (int tt = 0; tt < R0; ++tt) {
-                        const int iy = j0 + b * T + tt * (N / R0) - ge.pad;
-                        const bool ok = col_ok && iy >= 0 && iy < ge.nprb;
-                        pr[b * R0 + tt] = ok ? prb[(size_t)iy * ge.nprb + ix] * cinv : zero;
-                    }
-                cur_t = t;
-            }
-            if (!q.valid) {   // skipped position: exact zeros, as the memset of ptychofft.cu:69 leaves them
-                c32* tile_out = a.dst + (size_t)p * N * N;
-#pragma unroll
-                for (int s2 = 0; s2 < E; ++s2) tile_out[(size_t)(j0 + s2 * T) * N + x] = zero;
-                continue;
-            }
-        } else {
-            if (!q.valid) continue;
-            if (t != cur_t) {
-                if (cur_t >= 0) flush_probe(cur_t);
-#pragma unroll
-                for (int s2 = 0; s2 < E; ++s2) pr[s2] = zero;
-                cur_t = t;
-            }
-        }
-        // ---- slide / re-anchor the cached object window ----------------------------
-        const c32* ft = (MODE == M_FWD ? a.src : a.aux) + (size_t)t * ge.nz * ge.n;
-        const int Xa = q.sx + x0 - ge.pad;
-        const int Ra = q.sy, Rb = q.sy + ge.nprb + 1;
-        const bool colfit = (t == t_w) && Xa >= X0 && Xa + C < X0 + WC;
+    struct St { int p, t, Xa; Pos q; bool have; };
+    // decode position k and bring its object rows into the window (workgroup-uniform)
+    auto prepare = [&](int k, int kend) -> St {
+        St st;
+        st.have = k < kend;
+        st.p = 0; st.t = 0; st.Xa = 0; st.q = Pos{0, 0, 0.f, 0.f, false, false};
+        if (!st.have) return st;
+        st.p = a.order ? a.order[k] : k;
+        st.t = st.p / ge.nscan;
+        st.q = decode_pos(a.scan, st.p, ge);
+        if (!st.q.valid) return st;
+        const c32* ft = (MODE == M_FWD ? a.src : a.aux) + (size_t)st.t * ge.nz * ge.n;
+        st.Xa = st.q.sx + x0 - ge.pad;
+        const int Ra = st.q.sy, Rb = st.q.sy + ge.nprb + 1;
+        const bool colfit = (st.t == t_w) && st.Xa >= X0 && st.Xa + C < X0 + WC;
         if (!colfit) {
-            t_w = t;
-            X0 = (q.sx / kBucketPx) * kBucketPx + x0 - ge.pad;
+            t_w = st.t;
+            X0 = (st.q.sx / kBucketPx) * kBucketPx + x0 - ge.pad;
             Ylo = Ra; Yhi = Ra;
         } else if (Ra < Ylo || Ra > Yhi) {
             Ylo = Ra; Yhi = Ra;
@@ -633,38 +646,88 @@ __global__ __launch_bounds__(ColCfg<N>::NT) void k_cols_gatherwin(const ColArgs 
                 const int Y = Yhi + o / WC, col = o % WC;
                 const int X = X0 + col;
                 const bool inb = Y < ge.nz && X >= 0 && X < ge.n;
-                win[(Y % H) * WC + col] = inb ? ft[(size_t)Y * ge.n + X] : zero;
+                const c32 val = ft[inb ? ((size_t)Y * ge.n + X) : 0];
+                win[(Y % H) * WC + col] = inb ? val : zero;
             }
             Yhi = Rb;
         }
-        __syncthreads();
-        const float wx0 = 1.0f - q.fx, wy0 = 1.0f - q.fy;
-        const int colw = Xa - X0 + c;
-        auto patch = [&](int iy) {   // kernels.cu:97-104, taps from the LDS window
-            const int Y = q.sy + iy;
-            const c32* r0 = win + (Y % H) * WC + colw;
-            const c32* r1 = win + ((Y + 1) % H) * WC + colw;
-            return r0[0] * wx0 * wy0 + r0[1] * q.fx * wy0 + r1[0] * wx0 * q.fy + r1[1] * q.fx * q.fy;
-        };
+        return st;
+    };
 
-        c32 v[E];
-        if (MODE == M_FWD) {
+    const int kb = a.k_begin + seg * seglen;
+    const int ke = kb + seglen < a.k_end ? kb + seglen : a.k_end;
+    __syncthreads();
+    St st = prepare(kb, ke);
+    __syncthreads();
+    for (int k = kb; k < ke; ++k) {
+        if (MODE == M_FWD && st.t != cur_t) {
+            const c32* prb = a.aux + (size_t)st.t * ge.nprb * ge.nprb;
 #pragma unroll
             for (int b = 0; b < E / R0; ++b)
 #pragma unroll
                 for (int tt = 0; tt < R0; ++tt) {
                     const int iy = j0 + b * T + tt * (N / R0) - ge.pad;
                     const bool ok = col_ok && iy >= 0 && iy < ge.nprb;
-                    v[b * R0 + tt] = ok ? cmul(pr[b * R0 + tt], patch(iy)) : zero;
+                    const c32 w = prb[ok ? ((size_t)iy * ge.nprb + ix) : 0];
+                    pr[b * R0 + tt] = ok ? w * cinv : zero;
                 }
+            cur_t = st.t;
+        }
+        if (MODE == M_ADJ_PRB && st.q.valid && st.t != cur_t) {
+            if (cur_t >= 0) flush_probe(cur_t);
+#pragma unroll
+            for (int m = 0; m < E; ++m) pr[m] = zero;
+            cur_t = st.t;
+        }
+        if (!st.q.valid) {
+            if (MODE == M_FWD) {   // skipped position: exact zeros (memset of ptychofft.cu:69)
+                c32* tile_out = a.dst + (size_t)st.p * N * N;
+#pragma unroll
+                for (int m = 0; m < E; ++m) tile_out[(size_t)(j0 + m * T) * N + x] = zero;
+            }
+            __syncthreads();
+            st = prepare(k + 1, ke);
+            __syncthreads();
+            continue;
+        }
+        const Pos q = st.q;
+        const float w00 = (1.0f - q.fx) * (1.0f - q.fy), w01 = q.fx * (1.0f - q.fy);
+        const float w10 = (1.0f - q.fx) * q.fy, w11 = q.fx * q.fy;
+        // bilinear patch value of natural element m (row iy = j0 + m*T - pad); rows advance by T
+        // in the window, modulo H, without a division per element.  Padding rows read stale but
+        // finite window rows and are masked by the zero probe value / the select below.
+        const int colw = st.Xa - X0 + c;
+        int slot0 = (q.sy + j0 - ge.pad + 2 * H) % H;
+        auto patch_at = [&](int slot) {
+            const int s1 = slot + 1 == H ? 0 : slot + 1;
+            const c32* r0 = win + slot * WC + colw;
+            const c32* r1 = win + s1 * WC + colw;
+            return r0[0] * w00 + r0[1] * w01 + r1[0] * w10 + r1[1] * w11;   // kernels.cu:97-104
+        };
+
+        c32 v[E];
+        if (MODE == M_FWD) {
+            c32 nat[E];
+            int slot = slot0;
+#pragma unroll
+            for (int m = 0; m < E; ++m) {
+                nat[m] = patch_at(slot);
+                slot += T;
+                slot = slot >= H ? slot - H : slot;
+            }
+            F::from_natural(nat, v);
+#pragma unroll
+            for (int s2 = 0; s2 < E; ++s2) v[s2] = cmul(pr[s2], v[s2]);
         } else {
-            const c32* tile_in = a.src + (size_t)(a.natural_tiles ? p : (k - a.k_begin)) * N * N;
+            const c32* tile_in = a.src + (size_t)(a.natural_tiles ? st.p : (k - a.k_begin)) * N * N;
             fft.template load<0>(v, j0, [&](int i) { return tile_in[(size_t)i * N + x]; });
         }
         fft.template compute<0>(v);
+        St nx;
         if (P::NSTEP > 1) {
             fft.template store<0>(v, j0, [&](int i, c32 val) { lds[i * C + c] = val; });
             __syncthreads();
+            if (MODE == M_FWD) nx = prepare(k + 1, ke);   // window of k is no longer read
             fft.template load<1>(v, j0, [&](int i) { return lds[i * C + c]; });
             if (P::NSTEP > 2) {
                 __syncthreads();
@@ -674,24 +737,32 @@ __global__ __launch_bounds__(ColCfg<N>::NT) void k_cols_gatherwin(const ColArgs 
                 fft.template load<2>(v, j0, [&](int i) { return lds[i * C + c]; });
             }
             fft.template compute<LAST>(v);
+        } else if (MODE == M_FWD) {
+            __syncthreads();
+            nx = prepare(k + 1, ke);
         }
         if (MODE == M_FWD) {
-            c32* tile_out = a.dst + (size_t)p * N * N;
+            c32* tile_out = a.dst + (size_t)st.p * N * N;
             fft.template store<LAST>(v, j0, [&](int i, c32 val) { tile_out[(size_t)i * N + x] = val; });
+            __syncthreads();   // exchange buffer / new window rows visible to everyone
         } else {
+            c32 nat[E];
+            F::to_natural(v, nat);
+            int slot = slot0;
 #pragma unroll
-            for (int b = 0; b < E / RL; ++b) {
-                const int j = j0 + b * T;
-                const int base = (j / NsL) * NsL * RL + (j % NsL);
-#pragma unroll
-                for (int tt = 0; tt < RL; ++tt) {
-                    const int iy = base + tt * NsL - ge.pad;
-                    if (col_ok && iy >= 0 && iy < ge.nprb)
-                        pr[b * RL + tt] += cmulc(v[b * RL + brev(tt, ilog2(RL))], patch(iy));
-                }
+            for (int m = 0; m < E; ++m) {
+                const int iy = j0 + m * T - ge.pad;
+                const bool ok = col_ok && iy >= 0 && iy < ge.nprb;
+                const c32 term = cmulc(nat[m], patch_at(slot));
+                pr[m] += ok ? term : zero;
+                slot += T;
+                slot = slot >= H ? slot - H : slot;
             }
+            __syncthreads();   // everyone is done with the window of k and the exchange buffer
+            nx = prepare(k + 1, ke);
+            __syncthreads();
         }
-        __syncthreads();   // window and exchange buffer are rewritten by the next position
+        st = nx;
     }
     if (MODE == M_ADJ_PRB && cur_t >= 0) flush_probe(cur_t);
 }
