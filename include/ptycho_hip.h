@@ -99,14 +99,18 @@ int ptycho_cg_linesearch(ptycho_handle h, int slot1, int slot2, const void* data
                          void* stream);
 
 /* Tuning knobs: "chunk" (positions per launch pair, 0 = default);
- * "window" (1 = LDS overlap-add object adjoint [default], 0 = direct atomics). */
+ * "window" (1 = LDS overlap-add object adjoint [default], 0 = direct atomics);
+ * "team" (1 = forward operator as one persistent launch of per-XCD teams that keep the
+ * column->row intermediate in L2; experimental, default 0).  ptycho_get(h, 102) returns
+ * the abort word of the last team launch (non-zero = a bounded spin timed out). */
 int ptycho_set_option(ptycho_handle h, const char* name, long long value);
 
 /* In-library profiler for bench.py: when enabled, every kernel launch is
  * bracketed by HIP events on the caller's stream.  ptycho_profile_read waits for
  * the recorded launches, returns summed milliseconds and launch counts per kernel
  * (index 0 k_cols<FWD>, 1 k_rows<fwd>, 2 k_rows<inv>, 3 k_cols<ADJ_OBJ>,
- * 4 k_cols<ADJ_PRB>, 5 k_cols<PLAIN>, 6 position sort, 7-9 fused CG row passes; n >= 10)
+ * 4 k_cols<ADJ_PRB>, 5 k_cols<PLAIN>, 6 position sort, 7-9 fused CG row passes,
+ * 10 k_fwd_team; n >= 11)
  * and clears the record.
  * No counterpart in the reference (it has no timing code). */
 int ptycho_profile(ptycho_handle h, int enable);

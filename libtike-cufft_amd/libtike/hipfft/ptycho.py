@@ -134,6 +134,14 @@ class PtychoHIP:
         """Object adjoint: LDS overlap-add window (default) or direct atomics."""
         nat.check(nat.set_option(self._h, b"window", int(bool(on))))
 
+    def set_team(self, on=True):
+        """Forward operator as one persistent XCD-team launch (experimental)."""
+        nat.check(nat.set_option(self._h, b"team", int(bool(on))))
+
+    def team_aborted(self):
+        """True if the last team launch hit a spin bound (results are then invalid)."""
+        return int(nat.get(self._h, 102)) != 0
+
     def profile(self, enable=True):
         """Bracket every kernel launch with HIP events (bench.py's live timing)."""
         nat.check(nat.profile(self._h, int(bool(enable))))
