@@ -82,9 +82,8 @@ struct Pos {
 };
 
 // modff split of one scan position -- kernels.cu:27-28,39
-__device__ __forceinline__ Pos decode_pos(const float* __restrict__ scan, int p, const Geom& ge) {
+__device__ __forceinline__ Pos decode_xy(const float py, const float px, const Geom& ge) {
     Pos q;
-    const float py = scan[2 * (size_t)p], px = scan[2 * (size_t)p + 1];
     float iy, ix;
     q.fy = modff(py, &iy);
     q.fx = modff(px, &ix);
@@ -94,6 +93,27 @@ __device__ __forceinline__ Pos decode_pos(const float* __restrict__ scan, int p,
     q.sx = q.valid ? (int)ix : 0;
     q.inside = q.valid && (q.sy + ge.nprb + 1 <= ge.nz) && (q.sx + ge.nprb + 1 <= ge.n);
     return q;
+}
+__device__ __forceinline__ Pos decode_pos(const float* __restrict__ scan, int p, const Geom& ge) {
+    return decode_xy(scan[2 * (size_t)p], scan[2 * (size_t)p + 1], ge);
+}
+
+// positions of one run (<= kRunMax), staged in LDS once per workgroup so that the per-position
+// loop has no dependent global loads (order[k] -> scan[p]) on its critical path
+constexpr int kRunMax = 128;
+struct RunMeta {
+    int p[kRunMax];
+    float py[kRunMax], px[kRunMax];
+};
+__device__ __forceinline__ void load_run(RunMeta& rm, const int* __restrict__ order, const float* __restrict__ scan,
+                                         int kb, int ke, int tid) {
+    const int n = ke - kb;
+    for (int i = tid; i < n; i += (int)blockDim.x) {
+        const int p = order ? order[kb + i] : kb + i;
+        rm.p[i] = p;
+        rm.py[i] = scan[2 * (size_t)p];
+        rm.px[i] = scan[2 * (size_t)p + 1];
+    }
 }
 
 // kernels.cu:97-104 -- same taps, same left-to-right weight products
@@ -436,15 +456,17 @@ __global__ __launch_bounds__(ColCfg<N>::NT) void k_cols_adjwin(const ColArgs a, 
     const int kb = a.k_begin + seg * seglen;
     const int ke = kb + seglen < a.k_end ? kb + seglen : a.k_end;
 
+    __shared__ RunMeta rm;
+    load_run(rm, a.order, a.scan, kb, ke, tid);
     struct St { int p, t; Pos q; bool have; };
     auto decode = [&](int k) -> St {
         St st;
         st.have = k < ke;
         st.p = 0; st.t = 0; st.q = Pos{0, 0, 0.f, 0.f, false, false};
         if (!st.have) return st;
-        st.p = a.order ? a.order[k] : k;
+        st.p = rm.p[k - kb];
         st.t = st.p / ge.nscan;
-        st.q = decode_pos(a.scan, st.p, ge);
+        st.q = decode_xy(rm.py[k - kb], rm.px[k - kb], ge);
         return st;
     };
     auto tile_of = [&](const St& st, int k) {
@@ -616,16 +638,29 @@ __global__ __launch_bounds__(ColCfg<N>::NT) void k_cols_gatherwin(const ColArgs 
         }
     };
 
+    const int kb = a.k_begin + seg * seglen;
+    const int ke = kb + seglen < a.k_end ? kb + seglen : a.k_end;
+    __shared__ RunMeta rm;
+    load_run(rm, a.order, a.scan, kb, ke, tid);
+
     struct St { int p, t, Xa; Pos q; bool have; };
-    // decode position k and bring its object rows into the window (workgroup-uniform)
-    auto prepare = [&](int k, int kend) -> St {
+    // Window update for position k, split so that the global loads of the rows that slide in
+    // overlap the second half of the previous position's transform:
+    //   prepare_issue  decodes k (from LDS), slides / re-anchors the window (workgroup-uniform
+    //                  bookkeeping) and starts this thread's load of one new element;
+    //   prepare_commit stores it to the window.  A re-anchor (more new elements than threads)
+    //                  is loaded in place by prepare_issue.
+    c32 pre_val = zero;
+    int pre_slot = -1;
+    auto prepare_issue = [&](int k, int kend) -> St {
         St st;
         st.have = k < kend;
         st.p = 0; st.t = 0; st.Xa = 0; st.q = Pos{0, 0, 0.f, 0.f, false, false};
+        pre_slot = -1;
         if (!st.have) return st;
-        st.p = a.order ? a.order[k] : k;
+        st.p = rm.p[k - kb];
         st.t = st.p / ge.nscan;
-        st.q = decode_pos(a.scan, st.p, ge);
+        st.q = decode_xy(rm.py[k - kb], rm.px[k - kb], ge);
         if (!st.q.valid) return st;
         const c32* ft = (MODE == M_FWD ? a.src : a.aux) + (size_t)st.t * ge.nz * ge.n;
         st.Xa = st.q.sx + x0 - ge.pad;
@@ -642,20 +677,37 @@ __global__ __launch_bounds__(ColCfg<N>::NT) void k_cols_gatherwin(const ColArgs 
         }
         if (Rb > Yhi) {
             const int cnt = (Rb - Yhi) * WC;
-            for (int o = tid; o < cnt; o += NT) {
-                const int Y = Yhi + o / WC, col = o % WC;
-                const int X = X0 + col;
-                const bool inb = Y < ge.nz && X >= 0 && X < ge.n;
-                const c32 val = ft[inb ? ((size_t)Y * ge.n + X) : 0];
-                win[(Y % H) * WC + col] = inb ? val : zero;
+            if (cnt <= NT) {
+                if (tid < cnt) {
+                    const int Y = Yhi + tid / WC, col = tid % WC;
+                    const int X = X0 + col;
+                    const bool inb = Y < ge.nz && X >= 0 && X < ge.n;
+                    const c32 val = ft[inb ? ((size_t)Y * ge.n + X) : 0];
+                    pre_val = inb ? val : zero;
+                    pre_slot = (Y % H) * WC + col;
+                }
+            } else {
+                for (int o = tid; o < cnt; o += NT) {
+                    const int Y = Yhi + o / WC, col = o % WC;
+                    const int X = X0 + col;
+                    const bool inb = Y < ge.nz && X >= 0 && X < ge.n;
+                    const c32 val = ft[inb ? ((size_t)Y * ge.n + X) : 0];
+                    win[(Y % H) * WC + col] = inb ? val : zero;
+                }
             }
             Yhi = Rb;
         }
         return st;
     };
+    auto prepare_commit = [&]() {
+        if (pre_slot >= 0) win[pre_slot] = pre_val;
+    };
+    auto prepare = [&](int k, int kend) -> St {
+        St st = prepare_issue(k, kend);
+        prepare_commit();
+        return st;
+    };
 
-    const int kb = a.k_begin + seg * seglen;
-    const int ke = kb + seglen < a.k_end ? kb + seglen : a.k_end;
     __syncthreads();
     St st = prepare(kb, ke);
     __syncthreads();
@@ -727,7 +779,7 @@ __global__ __launch_bounds__(ColCfg<N>::NT) void k_cols_gatherwin(const ColArgs 
         if (P::NSTEP > 1) {
             fft.template store<0>(v, j0, [&](int i, c32 val) { lds[i * C + c] = val; });
             __syncthreads();
-            if (MODE == M_FWD) nx = prepare(k + 1, ke);   // window of k is no longer read
+            if (MODE == M_FWD) nx = prepare_issue(k + 1, ke);   // window of k is no longer read
             fft.template load<1>(v, j0, [&](int i) { return lds[i * C + c]; });
             if (P::NSTEP > 2) {
                 __syncthreads();
@@ -739,11 +791,12 @@ __global__ __launch_bounds__(ColCfg<N>::NT) void k_cols_gatherwin(const ColArgs 
             fft.template compute<LAST>(v);
         } else if (MODE == M_FWD) {
             __syncthreads();
-            nx = prepare(k + 1, ke);
+            nx = prepare_issue(k + 1, ke);
         }
         if (MODE == M_FWD) {
             c32* tile_out = a.dst + (size_t)st.p * N * N;
             fft.template store<LAST>(v, j0, [&](int i, c32 val) { tile_out[(size_t)i * N + x] = val; });
+            prepare_commit();
             __syncthreads();   // exchange buffer / new window rows visible to everyone
         } else {
             c32 nat[E];
@@ -1335,6 +1388,7 @@ int launch_adjwin(ptycho_handle h, ColArgs a, hipStream_t st) {
     if (nseg < 1) nseg = 1;
     int seglen = (np + nseg - 1) / nseg;
     if (seglen < 8) seglen = 8;
+    if (seglen > kRunMax) seglen = kRunMax;
     nseg = (np + seglen - 1) / seglen;
     {
         ProfSpan ps(h, K_COLS_ADJ_OBJ, st);
@@ -1353,6 +1407,7 @@ int launch_gatherwin(ptycho_handle h, ColArgs a, hipStream_t st) {
     if (nseg < 1) nseg = 1;
     int seglen = (np + nseg - 1) / nseg;
     if (seglen < 8) seglen = 8;
+    if (seglen > kRunMax) seglen = kRunMax;
     nseg = (np + seglen - 1) / seglen;
     {
         ProfSpan ps(h, MODE == M_FWD ? K_COLS_FWD : K_COLS_ADJ_PRB, st);
