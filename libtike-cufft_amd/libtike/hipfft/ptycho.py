@@ -295,11 +295,14 @@ def _upsampled_dft_batch(data, ups, upsample_factor, axis_offsets):
     def phase(off):                                                                   # [nb, ncol]
         return torch.exp(2j * np.pi * (off[:, None] * freq[None, :]).to(torch.complex128))
 
-    x = data.to(torch.complex128) * phase(axis_offsets[:, 1])[:, None, :]             # [nb, p, k]
+    # first axis (columns, k): tmp[i, p, j] = sum_k A[j, k] B1[i, k] data[i, p, k]
+    # (complex64 x complex128 promotes inside the multiply: one pass, no separate cast)
+    x = torch.mul(data, phase(axis_offsets[:, 1])[:, None, :])                        # [nb, p, k] c128
     tmp = torch.matmul(x, A.T)                                                        # [nb, p, j]
-    tmp = tmp.transpose(1, 2)                                                         # [nb, j, p]  (= einsum 'ijk,ipk->ijp')
-    y = tmp * phase(axis_offsets[:, 0])[:, None, :]                                   # second axis: k runs over p
-    return torch.matmul(y, A.T).transpose(1, 2)                                       # [nb, j2, j]
+    del x
+    # second axis (rows, p): rec[i, j2, j] = sum_p A[j2, p] B0[i, p] tmp[i, p, j]
+    tmp.mul_(phase(axis_offsets[:, 0])[:, :, None])
+    return torch.matmul(A, tmp)                                                       # [nb, j2, j]
 
 
 def _argmax2d(a):
