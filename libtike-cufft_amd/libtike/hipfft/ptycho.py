@@ -233,18 +233,45 @@ class PtychoHIP:
     def run(self, data, psi, scan, probe, **kwargs):
         raise NotImplementedError("Cannot run a base class.")
 
-    def run_batch(self, data, psi, scan, probe, **kwargs):
+    def run_batch(self, data, psi, scan, probe, angle_shard=None, **kwargs):
         """Run by dividing the work into angular partitions (``ptycho.py:135-162``).
-        NumPy in / NumPy out; ``scan`` updates are not returned and remainder
-        angles are dropped, as in the reference."""
+        NumPy in / NumPy out; ``scan`` updates are not returned and remainder angles are
+        dropped, as in the reference.
+
+        The reference uploads, solves and downloads one partition at a time, fully
+        synchronously.  Here the next partition's ``data / psi / scan / probe`` are staged
+        through pinned memory on a copy stream while the current partition is being solved
+        (angle streaming).  Angle partitions are independent problems, so a
+        multi-GPU job gives every rank its own partitions with no collective:
+        ``angle_shard=(rank, world)`` restricts this call to partitions ``rank, rank+world, ...``
+        (the other entries of the returned arrays keep their input values).
+        """
         assert probe.ndim == 4, "probe needs 4 dimensions, not %d" % probe.ndim
-        xp = self.array_module
         psi = psi.copy()
         probe = probe.copy()
-        for k in range(0, scan.shape[0] // self.ptheta):
-            ids = np.arange(k * self.ptheta, (k + 1) * self.ptheta)
-            result = self.run(xp.asarray(data[ids]), xp.asarray(psi[ids]),
-                              xp.asarray(scan[ids]), xp.asarray(probe[ids]), **kwargs)
+        nparts = scan.shape[0] // self.ptheta
+        rank, world = angle_shard if angle_shard is not None else (0, 1)
+        mine = list(range(nparts))[rank::world]
+        dev = self._device
+        copy_stream = torch.cuda.Stream(device=dev)
+
+        def stage(k):
+            ids = slice(k * self.ptheta, (k + 1) * self.ptheta)
+            with torch.cuda.stream(copy_stream):
+                t = [torch.from_numpy(np.ascontiguousarray(x[ids])).pin_memory().to(dev, non_blocking=True)
+                     for x in (data, psi, scan, probe)]
+                ev = torch.cuda.Event()
+                ev.record(copy_stream)
+            return ids, t, ev
+
+        staged = stage(mine[0]) if mine else None
+        for n, k in enumerate(mine):
+            ids, (d_gpu, psi_gpu, scan_gpu, prb_gpu), ev = staged
+            torch.cuda.current_stream().wait_event(ev)
+            for t in (d_gpu, psi_gpu, scan_gpu, prb_gpu):
+                t.record_stream(torch.cuda.current_stream())
+            staged = stage(mine[n + 1]) if n + 1 < len(mine) else None
+            result = self.run(d_gpu, psi_gpu, scan_gpu, prb_gpu, **kwargs)
             psi[ids] = self.asnumpy(result["psi"])
             probe[ids] = self.asnumpy(result["probe"])
         return {"psi": psi, "probe": probe}

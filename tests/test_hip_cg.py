@@ -84,6 +84,31 @@ def test_fused_loop_matches_unfused_with_padded_probe(pt):
     assert np.abs(rf["psi"] - want["psi"]).max() < 2e-4
 
 
+def test_run_batch_streams_angle_partitions(pt):
+    """run_batch over several independent angles (prefetch on a copy stream) equals solving
+    each angle on its own; angle_shard splits the partitions over ranks without a collective."""
+    p, probe, ora, data = setup()
+    nang = 3
+    rng = np.random.default_rng(1)
+    psis = np.concatenate([np.ones_like(p["psi"])] * nang)
+    scans = np.concatenate([p["scan"] + rng.random(p["scan"].shape).astype(np.float32) * 0.3 for _ in range(nang)])
+    probes = np.concatenate([probe * (1 + 0.1 * a) for a in range(nang)])
+    datas = np.concatenate([(np.abs(ora.fwd(p["psi"], scans[a:a + 1], probes[a:a + 1, 0])) ** 2).astype(np.float32)
+                            for a in range(nang)])
+    with pt.CGPtychoSolver(p["nscan"], 32, 32, 1, p["nz"], p["n"]) as slv:
+        slv.verbose = False
+        full = slv.run_batch(datas, psis, scans, probes, piter=3)
+        single = [slv.run_batch(datas[a:a + 1], psis[a:a + 1], scans[a:a + 1], probes[a:a + 1], piter=3)
+                  for a in range(nang)]
+        shard = slv.run_batch(datas, psis, scans, probes, piter=3, angle_shard=(1, 2))
+    for a in range(nang):
+        np.testing.assert_allclose(full["psi"][a], single[a]["psi"][0], atol=2e-5)
+        np.testing.assert_allclose(full["probe"][a], single[a]["probe"][0], atol=2e-5)
+    np.testing.assert_allclose(shard["psi"][1], full["psi"][1], atol=2e-5)       # rank 1 of 2 owns angle 1
+    np.testing.assert_array_equal(shard["psi"][0], psis[0])                      # others untouched
+    np.testing.assert_array_equal(shard["psi"][2], psis[2])
+
+
 def test_cg_gradient_vanishes_at_truth(pt):
     p, probe, ora, data = setup()
     with pt.CGPtychoSolver(p["nscan"], 32, 32, 1, p["nz"], p["n"]) as slv:
