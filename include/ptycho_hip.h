@@ -98,6 +98,25 @@ int ptycho_cg_linesearch(ptycho_handle h, int slot1, int slot2, const void* data
                          const double* ab, double gamma0, int ncand, double* costs,
                          void* stream);
 
+/* Multi-mode variants (ptycho.py:330-333,349-356,386-391,425-434 loop over probe modes):
+ * the summed intensity and the line-search terms p1,p2,p3 are float32 arrays
+ * [ptheta][nscan][ndet][ndet] owned by the caller.
+ *   ptycho_cg_accum_intensity  inten (first ? = : +=) |g|^2 of the slot
+ *   ptycho_cg_array_stats      sums += { sum sqrt(inten d), sum inten }
+ *   ptycho_cg_project_multi    as ptycho_cg_project with I = inten * (a/b)^2 (slot from the rescaled probe)
+ *   ptycho_cg_accum_terms      p1,p2,p3 (first ? = : +=) |t1|^2, |t2|^2, 2 Re(t1 conj t2)
+ *   ptycho_cg_array_costs      as ptycho_cg_linesearch on stored p1,p2,p3 */
+int ptycho_cg_accum_intensity(ptycho_handle h, int slot, void* inten, int first, void* stream);
+int ptycho_cg_array_stats(ptycho_handle h, const void* inten, const void* data, double* sums,
+                          void* stream);
+int ptycho_cg_project_multi(ptycho_handle h, int src_slot, int dst_slot, const void* data,
+                            const void* inten, const double* ab, double* cost, void* stream);
+int ptycho_cg_accum_terms(ptycho_handle h, int slot1, int slot2, void* p1, void* p2, void* p3,
+                          int first, void* stream);
+int ptycho_cg_array_costs(ptycho_handle h, const void* p1, const void* p2, const void* p3,
+                          const void* data, double gamma0, int ncand, double* costs,
+                          void* stream);
+
 /* Tuning knobs: "chunk" (positions per launch pair, 0 = default);
  * "window" (1 = LDS overlap-add object adjoint [default], 0 = direct atomics);
  * "team" (1 = forward operator as one persistent launch of per-XCD teams that keep the
@@ -110,7 +129,7 @@ int ptycho_set_option(ptycho_handle h, const char* name, long long value);
  * the recorded launches, returns summed milliseconds and launch counts per kernel
  * (index 0 k_cols<FWD>, 1 k_rows<fwd>, 2 k_rows<inv>, 3 k_cols<ADJ_OBJ>,
  * 4 k_cols<ADJ_PRB>, 5 k_cols<PLAIN>, 6 position sort, 7-9 fused CG row passes,
- * 10 k_fwd_team; n >= 11)
+ * 10 k_fwd_team, 11 accumulate row passes, 12 array reductions; n >= 13)
  * and clears the record.
  * No counterpart in the reference (it has no timing code). */
 int ptycho_profile(ptycho_handle h, int enable);

@@ -851,7 +851,7 @@ __global__ void k_sort_keys(const float* __restrict__ scan, const Geom ge, const
 //                 sum (sqrt|p1 + y^2 p2 + y p3| - sqrt d)^2 for y = gamma0 * 2^-j, j < ncand,
 //                 plus f(p1) -- every trial of line_search_sqr in one pass (ptycho.py:253-281)
 // ---------------------------------------------------------------------------
-enum RowEp { EP_STATS = 1, EP_PROJECT = 2, EP_LINESEARCH = 3 };
+enum RowEp { EP_STATS = 1, EP_PROJECT = 2, EP_LINESEARCH = 3, EP_ACCUM_I = 4, EP_ACCUM_P = 5 };
 constexpr int kMaxCand = 16;
 
 struct RowFusedArgs {
@@ -866,6 +866,12 @@ struct RowFusedArgs {
     float gamma0;
     int ncand;
     int xa, xb;          // columns outside [xa, xb) of the inputs are zero (never written)
+    // multi-mode variants (arrays are float32 [positions][ndet][ndet])
+    const float* inten;  // EP_PROJECT: summed intensity of all modes (nullptr: single mode, |g|^2)
+    float* acc1;         // EP_ACCUM_I: intensity;  EP_ACCUM_P: p1
+    float* acc2;         // EP_ACCUM_P: p2
+    float* acc3;         // EP_ACCUM_P: p3
+    int first;           // 1: overwrite the arrays, 0: add to them
 };
 
 template <int N, int EP>
@@ -875,7 +881,7 @@ __global__ __launch_bounds__(256) void k_rows_fused(const RowFusedArgs a) {
     using L = RowLds<N>;
     constexpr int E = P::E, T = P::T, B = 256 / T;
     constexpr int LAST = P::NSTEP - 1;
-    constexpr int NACC = EP == EP_STATS ? 2 : (EP == EP_PROJECT ? 1 : kMaxCand + 1);
+    constexpr int NACC = EP == EP_STATS ? 2 : (EP == EP_LINESEARCH ? kMaxCand + 1 : 1);
     __shared__ c32 lds[P::NSTEP > 1 ? B * L::FS : 1];
     __shared__ double red[4 * NACC];
 
@@ -925,8 +931,10 @@ __global__ __launch_bounds__(256) void k_rows_fused(const RowFusedArgs a) {
         fft.template load<0>(v, j0, [&](int i) { return (ok && i >= a.xa && i < a.xb) ? a.s1[rowoff + i] : zero; });
         fwd_row(v, g1);
         float d[E];
+        if (EP != EP_ACCUM_I && EP != EP_ACCUM_P) {
 #pragma unroll
-        for (int m = 0; m < E; ++m) d[m] = ok ? a.data[rowoff + j0 + m * T] : 0.0f;
+            for (int m = 0; m < E; ++m) d[m] = ok ? a.data[rowoff + j0 + m * T] : 0.0f;
+        }
 
         if (EP == EP_STATS) {
 #pragma unroll
@@ -935,13 +943,41 @@ __global__ __launch_bounds__(256) void k_rows_fused(const RowFusedArgs a) {
                 acc[0] += sqrtf(I * d[m]);
                 acc[1] += I;
             }
+        } else if (EP == EP_ACCUM_I) {
+            if (ok) {
+#pragma unroll
+                for (int m = 0; m < E; ++m) {
+                    const float I = g1[m].x * g1[m].x + g1[m].y * g1[m].y;
+                    float* o = a.acc1 + rowoff + j0 + m * T;
+                    *o = a.first ? I : *o + I;
+                }
+            }
+        } else if (EP == EP_ACCUM_P) {
+            c32 g2[E];
+            fft.template load<0>(v, j0, [&](int i) { return (ok && i >= a.xa && i < a.xb) ? a.s2[rowoff + i] : zero; });
+            fwd_row(v, g2);
+            if (ok) {
+#pragma unroll
+                for (int m = 0; m < E; ++m) {
+                    const size_t o = rowoff + j0 + m * T;
+                    const float p1 = g1[m].x * g1[m].x + g1[m].y * g1[m].y;
+                    const float p2 = g2[m].x * g2[m].x + g2[m].y * g2[m].y;
+                    const float p3 = 2.0f * (g1[m].x * g2[m].x + g1[m].y * g2[m].y);
+                    a.acc1[o] = a.first ? p1 : a.acc1[o] + p1;
+                    a.acc2[o] = a.first ? p2 : a.acc2[o] + p2;
+                    a.acc3[o] = a.first ? p3 : a.acc3[o] + p3;
+                }
+            }
         } else if (EP == EP_PROJECT) {
             const float s2 = s * s;
             c32 rr[E];
 #pragma unroll
             for (int m = 0; m < E; ++m) {
-                const float I = (g1[m].x * g1[m].x + g1[m].y * g1[m].y) * s2;
-                const c32 fp = (g1[m] * s) * sinv;
+                // single mode: S comes from the unscaled probe -> I' = |g|^2 s^2, fpsi = (g s)(1/s');
+                // multi mode: S comes from the rescaled probe and I is the summed intensity array
+                const float I = a.inten ? (ok ? a.inten[rowoff + j0 + m * T] : 0.0f) * s2
+                                        : (g1[m].x * g1[m].x + g1[m].y * g1[m].y) * s2;
+                const c32 fp = a.inten ? g1[m] * sinv : (g1[m] * s) * sinv;
                 const float sd = sqrtf(d[m]), sI = sqrtf(I);
                 rr[m] = fp - (fp * sd) / (sI + 1e-32f);
                 const float df = sI - sd;
@@ -993,6 +1029,7 @@ __global__ __launch_bounds__(256) void k_rows_fused(const RowFusedArgs a) {
             }
         }
     }
+    if (EP == EP_ACCUM_I || EP == EP_ACCUM_P) return;
     // ---- block reduction (float partials -> double), one atomic per value per workgroup
     const int lane = tid & 63, wave = tid >> 6;
 #pragma unroll
@@ -1007,6 +1044,56 @@ __global__ __launch_bounds__(256) void k_rows_fused(const RowFusedArgs a) {
         const double x = red[tid] + red[NACC + tid] + red[2 * NACC + tid] + red[3 * NACC + tid];
         if (EP != EP_LINESEARCH || tid < a.ncand || tid == kMaxCand)
             atomicAdd(a.sums + (EP == EP_LINESEARCH && tid == kMaxCand ? a.ncand : tid), x);
+    }
+}
+
+// elementwise reductions over stored arrays (multi-mode CG path): no DFT involved
+//   MODE 0: sums += { sum sqrt(I d), sum I }                                   (ptycho.py:342-343)
+//   MODE 1: costs[j] += sum (sqrt|p1 + y_j^2 p2 + y_j p3| - sqrt d)^2, costs[ncand] += f(p1)
+template <int MODE>
+__global__ __launch_bounds__(256) void k_array_reduce(const float* __restrict__ p1, const float* __restrict__ p2,
+                                                      const float* __restrict__ p3, const float* __restrict__ d,
+                                                      const long long n, const float gamma0, const int ncand,
+                                                      double* __restrict__ sums) {
+    constexpr int NACC = MODE == 0 ? 2 : kMaxCand + 1;
+    __shared__ double red[4 * NACC];
+    float acc[NACC];
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) acc[i] = 0.0f;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const float dd = d[i];
+        if (MODE == 0) {
+            const float I = p1[i];
+            acc[0] += sqrtf(I * dd);
+            acc[1] += I;
+        } else {
+            const float a1 = p1[i], a2 = p2[i], a3 = p3[i];
+            const float sd = sqrtf(dd);
+            float df = sqrtf(fabsf(a1)) - sd;
+            acc[kMaxCand] += df * df;
+            float gam = gamma0;
+#pragma unroll
+            for (int j = 0; j < kMaxCand; ++j) {
+                if (j < ncand) {
+                    df = sqrtf(fabsf(a1 + (gam * gam) * a2 + gam * a3)) - sd;
+                    acc[j] += df * df;
+                }
+                gam *= 0.5f;
+            }
+        }
+    }
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) {
+        double x = (double)acc[i];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) x += __shfl_down(x, off, 64);
+        if (lane == 0) red[wave * NACC + i] = x;
+    }
+    __syncthreads();
+    if (tid < NACC) {
+        const double x = red[tid] + red[NACC + tid] + red[2 * NACC + tid] + red[3 * NACC + tid];
+        if (MODE == 0 || tid < ncand || tid == kMaxCand) atomicAdd(sums + (MODE == 1 && tid == kMaxCand ? ncand : tid), x);
     }
 }
 
@@ -1274,7 +1361,7 @@ __global__ __launch_bounds__(256) void k_fwd_team(const TeamArgs a) {
 thread_local std::string g_err;
 
 // kernel ids for the in-library profiler (ptycho_profile_read)
-enum { K_COLS_FWD = 0, K_ROWS_FWD = 1, K_ROWS_INV = 2, K_COLS_ADJ_OBJ = 3, K_COLS_ADJ_PRB = 4, K_COLS_PLAIN = 5, K_SORT = 6, K_ROWS_STATS = 7, K_ROWS_PROJECT = 8, K_ROWS_LINESEARCH = 9, K_FWD_TEAM = 10, K_COUNT = 11 };
+enum { K_COLS_FWD = 0, K_ROWS_FWD = 1, K_ROWS_INV = 2, K_COLS_ADJ_OBJ = 3, K_COLS_ADJ_PRB = 4, K_COLS_PLAIN = 5, K_SORT = 6, K_ROWS_STATS = 7, K_ROWS_PROJECT = 8, K_ROWS_LINESEARCH = 9, K_FWD_TEAM = 10, K_ROWS_ACCUM = 11, K_ARRAY_REDUCE = 12, K_COUNT = 13 };
 
 int fail(int code, const std::string& msg) {
     g_err = msg;
@@ -1653,7 +1740,7 @@ int do_cg_rows(ptycho_handle h, RowFusedArgs a, hipStream_t st) {
     long long nb = (a.nrows + B - 1) / B;
     long long grid = nb < (long long)h->n_cu * 8 ? nb : (long long)h->n_cu * 8;
     {
-        ProfSpan ps(h, EP == EP_STATS ? K_ROWS_STATS : EP == EP_PROJECT ? K_ROWS_PROJECT : K_ROWS_LINESEARCH, st);
+        ProfSpan ps(h, EP == EP_STATS ? K_ROWS_STATS : EP == EP_PROJECT ? K_ROWS_PROJECT : EP == EP_LINESEARCH ? K_ROWS_LINESEARCH : K_ROWS_ACCUM, st);
         hipLaunchKernelGGL((k_rows_fused<N, EP>), dim3((unsigned)grid), dim3(256), 0, st, a);
     }
     HIP_TRY(hipGetLastError());
@@ -1839,7 +1926,7 @@ int ptycho_profile(ptycho_handle h, int enable) {
 int ptycho_profile_read(ptycho_handle h, double* ms, long long* launches, int n) {
     int rc = check_handle(h);
     if (rc) return rc;
-    if (!ms || !launches || n < K_COUNT) return fail(PTYCHO_ERR_ARG, "need arrays of at least 11 entries");
+    if (!ms || !launches || n < K_COUNT) return fail(PTYCHO_ERR_ARG, "need arrays of at least 13 entries");
     for (int i = 0; i < n; ++i) { ms[i] = 0.0; launches[i] = 0; }
     for (auto& sp : h->spans) {
         HIP_TRY(hipEventSynchronize(sp.b));
@@ -1929,6 +2016,77 @@ int ptycho_cg_linesearch(ptycho_handle h, int slot1, int slot2, const void* data
     a.gamma0 = (float)gamma0; a.ncand = ncand;
     hipStream_t st = (hipStream_t)stream;
     PTY_DISPATCH(h->ge.ndet, (do_cg_rows<NN, EP_LINESEARCH>(h, a, st)));
+}
+
+int ptycho_cg_project_multi(ptycho_handle h, int src_slot, int dst_slot, const void* data, const void* inten,
+                            const double* ab, double* cost, void* stream) {
+    int rc = check_handle(h);
+    if (rc) return rc;
+    if (!data || !cost || !inten) return fail(PTYCHO_ERR_ARG, "null operand");
+    if (src_slot < 0 || src_slot > 1 || !h->work[src_slot]) return fail(PTYCHO_ERR_ARG, "work slot is empty");
+    rc = ensure_work(h, dst_slot);
+    if (rc) return rc;
+    RowFusedArgs a{};
+    a.s1 = h->work[src_slot]; a.out = h->work[dst_slot]; a.data = (const float*)data; a.sums = cost; a.ab = ab;
+    a.inten = (const float*)inten;
+    hipStream_t st = (hipStream_t)stream;
+    PTY_DISPATCH(h->ge.ndet, (do_cg_rows<NN, EP_PROJECT>(h, a, st)));
+}
+
+int ptycho_cg_accum_intensity(ptycho_handle h, int slot, void* inten, int first, void* stream) {
+    int rc = check_handle(h);
+    if (rc) return rc;
+    if (!inten) return fail(PTYCHO_ERR_ARG, "null operand");
+    if (slot < 0 || slot > 1 || !h->work[slot]) return fail(PTYCHO_ERR_ARG, "work slot is empty");
+    RowFusedArgs a{};
+    a.s1 = h->work[slot]; a.acc1 = (float*)inten; a.first = first;
+    hipStream_t st = (hipStream_t)stream;
+    PTY_DISPATCH(h->ge.ndet, (do_cg_rows<NN, EP_ACCUM_I>(h, a, st)));
+}
+
+int ptycho_cg_accum_terms(ptycho_handle h, int slot1, int slot2, void* p1, void* p2, void* p3, int first, void* stream) {
+    int rc = check_handle(h);
+    if (rc) return rc;
+    if (!p1 || !p2 || !p3) return fail(PTYCHO_ERR_ARG, "null operand");
+    if (slot1 < 0 || slot1 > 1 || slot2 < 0 || slot2 > 1 || !h->work[slot1] || !h->work[slot2])
+        return fail(PTYCHO_ERR_ARG, "work slot is empty");
+    RowFusedArgs a{};
+    a.s1 = h->work[slot1]; a.s2 = h->work[slot2]; a.acc1 = (float*)p1; a.acc2 = (float*)p2; a.acc3 = (float*)p3;
+    a.first = first;
+    hipStream_t st = (hipStream_t)stream;
+    PTY_DISPATCH(h->ge.ndet, (do_cg_rows<NN, EP_ACCUM_P>(h, a, st)));
+}
+
+int ptycho_cg_array_stats(ptycho_handle h, const void* inten, const void* data, double* sums, void* stream) {
+    int rc = check_handle(h);
+    if (rc) return rc;
+    if (!inten || !data || !sums) return fail(PTYCHO_ERR_ARG, "null operand");
+    const long long n = (long long)h->ge.ptheta * h->ge.nscan * h->ge.ndet * h->ge.ndet;
+    hipStream_t st = (hipStream_t)stream;
+    {
+        ProfSpan ps(h, K_ARRAY_REDUCE, st);
+        hipLaunchKernelGGL((k_array_reduce<0>), dim3((unsigned)(h->n_cu * 8)), dim3(256), 0, st, (const float*)inten,
+                           (const float*)nullptr, (const float*)nullptr, (const float*)data, n, 0.0f, 0, sums);
+    }
+    HIP_TRY(hipGetLastError());
+    return PTYCHO_OK;
+}
+
+int ptycho_cg_array_costs(ptycho_handle h, const void* p1, const void* p2, const void* p3, const void* data,
+                          double gamma0, int ncand, double* costs, void* stream) {
+    int rc = check_handle(h);
+    if (rc) return rc;
+    if (!p1 || !p2 || !p3 || !data || !costs) return fail(PTYCHO_ERR_ARG, "null operand");
+    if (ncand < 1 || ncand > kMaxCand) return fail(PTYCHO_ERR_ARG, "ncand must be in [1, 16]");
+    const long long n = (long long)h->ge.ptheta * h->ge.nscan * h->ge.ndet * h->ge.ndet;
+    hipStream_t st = (hipStream_t)stream;
+    {
+        ProfSpan ps(h, K_ARRAY_REDUCE, st);
+        hipLaunchKernelGGL((k_array_reduce<1>), dim3((unsigned)(h->n_cu * 8)), dim3(256), 0, st, (const float*)p1,
+                           (const float*)p2, (const float*)p3, (const float*)data, n, (float)gamma0, ncand, costs);
+    }
+    HIP_TRY(hipGetLastError());
+    return PTYCHO_OK;
 }
 
 int ptycho_fft2(ptycho_handle h, void* dst, const void* src, size_t nbatch, int dir, void* stream) {

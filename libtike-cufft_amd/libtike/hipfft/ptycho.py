@@ -523,6 +523,132 @@ class CGPtychoSolver(PtychoHIP):
                     print("%4d, %.3e, %.3e, %.7e" % self.history[-1])
         return {"psi": psi, "probe": probe}
 
+    # -- fused multi-mode gaussian loop ----------------------------------------------------
+    def _array_line_search(self, p1, p2, p3, data, costs):
+        gamma0 = 1.0
+        while True:
+            costs.zero_()
+            nat.check(nat.cg_array_costs(self._h, _ptr(p1), _ptr(p2), _ptr(p3), _ptr(data), gamma0, 16,
+                                         _ptr(costs), _stream()))
+            self._allreduce(costs)
+            c = costs.to(torch.float32).cpu().numpy()
+            step = gamma0
+            for j in range(16):
+                if not (c[j] > c[16]):
+                    return step
+                if step < 1e-32:
+                    warnings.warn("Line search failed for conjugate gradient.")
+                    return 0
+                step *= 0.5
+            gamma0 = step
+
+    def _run_fused_multi(self, data, psi, scan, probe, piter, recover_prb):
+        """``CGPtychoSolver.run`` (ptycho.py:283-488), gaussian model, any number of
+        incoherent probe modes.  The summed intensity and the line-search terms are kept as
+        float32 arrays (they are sums over modes *before* the nonlinearity); every farplane
+        itself stays in the row pass's registers (C ABI ``ptycho_cg_*``)."""
+        dev = data.device
+        M = probe.shape[1]
+        data = self._operand(data, torch.float32, (self.ptheta, self.nscan, self.ndet, self.ndet), "data")
+        psi = self._operand(psi, torch.complex64, (self.ptheta, self.nz, self.n), "psi")
+        self._operand(scan, torch.float32, (self.ptheta, self.nscan, 2), "scan")
+        assert probe.dtype == torch.complex64
+        nscan_total = self._nscan_total()
+        sums = torch.zeros(2, dtype=torch.float64, device=dev)
+        cost = torch.zeros(1, dtype=torch.float64, device=dev)
+        scratch_cost = torch.zeros(1, dtype=torch.float64, device=dev)
+        costs = torch.zeros(17, dtype=torch.float64, device=dev)
+        inten = torch.empty_like(data)
+        p1, p2, p3 = torch.empty_like(data), torch.empty_like(data), torch.empty_like(data)
+        mode = lambda arr, k: arr[:, k].contiguous()
+
+        def total_intensity(slot):
+            for k in range(M):
+                self._cg_fwd_cols(slot, psi, scan, mode(probe, k))
+                nat.check(nat.cg_accum_intensity(self._h, slot, _ptr(inten), int(k == 0), _stream()))
+
+        dpsi = gradpsi0 = None
+        dprb = gradprb0 = gradprb = None
+        gammaprb = 0
+        if self.verbose:
+            print("# congujate gradient parameters\n"
+                  "iteration, step size object, step size probe, function min")
+        for i in range(piter):
+            # 1) object step ------------------------------------------------------------
+            total_intensity(0)                                                  # :329-333
+            sums.zero_()
+            nat.check(nat.cg_array_stats(self._h, _ptr(inten), _ptr(data), _ptr(sums), _stream()))
+            self._allreduce(sums)
+            ab32 = sums.to(torch.float32)
+            probe *= (ab32[0] / ab32[1])                                        # :344
+            gradpsi = torch.zeros((self.ptheta, self.nz, self.n), dtype=torch.complex64, device=dev)
+            cost.zero_()
+            for k in range(M):                                                  # :349-356
+                pk = mode(probe, k)
+                self._cg_fwd_cols(0, psi, scan, pk)
+                nat.check(nat.cg_project_multi(self._h, 0, 1, _ptr(data), _ptr(inten), _ptr(sums),
+                                               _ptr(cost if k == 0 else scratch_cost), _stream()))
+                g = torch.zeros_like(gradpsi)
+                nat.check(nat.cg_adj_cols(self._h, 1, _ptr(g), _ptr(scan), _ptr(pk), 0, _stream()))
+                gradpsi += g / (torch.max(torch.abs(pk)) ** 2)
+            self._allreduce(gradpsi)
+            dpsi = _dy_direction(i, gradpsi, gradpsi0, dpsi)
+            gradpsi0 = gradpsi
+            for k in range(M):                                                  # :383-391
+                pk = mode(probe, k)
+                self._cg_fwd_cols(0, psi, scan, pk)
+                self._cg_fwd_cols(1, dpsi, scan, pk)
+                nat.check(nat.cg_accum_terms(self._h, 0, 1, _ptr(p1), _ptr(p2), _ptr(p3), int(k == 0), _stream()))
+            gammapsi = 0.5 * self._array_line_search(p1, p2, p3, data, costs)
+
+            if i > 0:                                                           # :398-403
+                ones = probe[:, 0] * 0 + 1
+                tmp1 = self.fwd(psi, scan, ones)[0]
+                tmp2 = self.fwd(psi + gammapsi * dpsi, scan, ones)[0]
+                shifts = register_translation_batch(self, tmp1, tmp2, upsample_factor=100,
+                                                    space="fourier")
+                scan[0, :] += shifts.to(scan.dtype)
+                del tmp1, tmp2
+            psi = psi + gammapsi * dpsi
+
+            # 2) probe step, one mode at a time ------------------------------------------
+            if recover_prb:                                                     # :409-465
+                if i == 0:
+                    gradprb = probe * 0
+                    gradprb0 = probe * 0
+                    dprb = probe * 0
+                for m in range(M):
+                    self._cg_fwd_cols(0, psi, scan, mode(probe, m))             # fprb
+                    total_intensity(1)                                          # absfprb (= p1 below)
+                    scratch_cost.zero_()
+                    nat.check(nat.cg_project_multi(self._h, 0, 1, _ptr(data), _ptr(inten), None,
+                                                   _ptr(scratch_cost), _stream()))
+                    g = torch.zeros((self.ptheta, self.nprb, self.nprb), dtype=torch.complex64, device=dev)
+                    nat.check(nat.cg_adj_cols(self._h, 1, _ptr(psi), _ptr(scan), _ptr(g), 1, _stream()))
+                    self._allreduce(g)
+                    gradprb[:, m] = g / torch.max(torch.abs(psi)) ** 2 / nscan_total * M
+                    if i == 0:
+                        dprb[:, m] = -gradprb[:, m]
+                    else:
+                        dprb[:, m] = -gradprb[:, m] + (
+                            torch.linalg.norm(gradprb[:, m]) ** 2
+                            / (torch.sum(torch.conj(dprb[:, m]) * (gradprb[:, m] - gradprb0[:, m])))
+                            * dprb[:, m])
+                    gradprb0[:, m] = gradprb[:, m]
+                    self._cg_fwd_cols(0, psi, scan, mode(probe, m))
+                    self._cg_fwd_cols(1, psi, scan, mode(dprb, m))
+                    nat.check(nat.cg_accum_terms(self._h, 0, 1, _ptr(p1), _ptr(p2), _ptr(p3), 1, _stream()))
+                    gammaprb = 0.5 * self._array_line_search(inten, p2, p3, data, costs)
+                    probe[:, m] = probe[:, m] + gammaprb * dprb[:, m]
+
+            if i % self.log_every == 0:
+                c = cost.clone()
+                self._allreduce(c)
+                self.history.append((i, float(gammapsi), float(gammaprb), float(c.to(torch.float32))))
+                if self.verbose:
+                    print("%4d, %.3e, %.3e, %.7e" % self.history[-1])
+        return {"psi": psi, "probe": probe}
+
     def run(self, data, psi, scan, probe, piter, model="gaussian",
             recover_prb=False, ortho_prb=False):
         """Conjugate gradients for ptychography (``ptycho.py:283-488``).
@@ -531,8 +657,10 @@ class CGPtychoSolver(PtychoHIP):
         """
         assert probe.ndim == 4, "probe needs 4 dimensions, not %d" % probe.ndim
         nmodes = probe.shape[1]
-        if self.fused and nmodes == 1 and model == "gaussian":
-            return self._run_fused(data, psi, scan, probe, piter, recover_prb)
+        if self.fused and model == "gaussian":
+            if nmodes == 1:
+                return self._run_fused(data, psi, scan, probe, piter, recover_prb)
+            return self._run_fused_multi(data, psi, scan, probe, piter, recover_prb)
         nscan_total = self._nscan_total()
 
         def minf(fpsi):

@@ -84,6 +84,27 @@ def test_fused_loop_matches_unfused_with_padded_probe(pt):
     assert np.abs(rf["psi"] - want["psi"]).max() < 2e-4
 
 
+def test_fused_multimode_matches_unfused(pt):
+    """Three probe modes (the /root/reference/tests/test_modes.py scenario shape), fused
+    multi-mode kernels against the statement-by-statement torch loop and the oracle."""
+    p, probe, ora, data = setup(3)
+    start = probe.copy().swapaxes(2, 3)
+    out = []
+    for fused in (True, False):
+        with pt.CGPtychoSolver(p["nscan"], 32, 32, 1, p["nz"], p["n"]) as slv:
+            slv.verbose, slv.log_every, slv.fused = False, 1, fused
+            res = slv.run_batch(data.copy(), np.ones_like(p["psi"]), p["scan"].copy(), start.copy(),
+                                piter=4, recover_prb=True)
+            out.append((res, list(slv.history)))
+    (rf, hf), (ru, hu) = out
+    for a, b in zip(hf, hu):
+        assert a[:3] == b[:3] and abs(a[3] - b[3]) <= 1e-4 * abs(b[3]), (a, b)
+    assert np.abs(rf["psi"] - ru["psi"]).max() < 2e-4
+    assert np.abs(rf["probe"] - ru["probe"]).max() < 2e-4 * np.abs(ru["probe"]).max()
+    want = ora.run(data.copy(), np.ones_like(p["psi"]), p["scan"].copy(), start.copy(), piter=4, recover_prb=True)
+    assert np.abs(rf["psi"] - want["psi"]).max() < 2e-4
+
+
 def test_run_batch_streams_angle_partitions(pt):
     """run_batch over several independent angles (prefetch on a copy stream) equals solving
     each angle on its own; angle_shard splits the partitions over ranks without a collective."""
