@@ -1392,6 +1392,8 @@ struct ptycho_handle_s {
     c32* work[2] = {nullptr, nullptr};   // CG work buffers (column-pass intermediates), all positions
     int use_window = 1;       // 0: direct-atomics object adjoint (k_cols<ADJ_OBJ>)
     int use_team = 0;         // 1: forward operator as one persistent XCD-team launch (experimental)
+    int trust_order = 0;      // 1: caller vouches that scan is unchanged since the last sort
+    const float* order_scan = nullptr;   // scan pointer the current order was computed from
     c32* ring = nullptr;      // team ring: 8 XCD x 2 x Q tiles
     unsigned* ctrl = nullptr; // team control words
     int team_R = 0, team_Q = 0;
@@ -1767,6 +1769,10 @@ int check_handle(ptycho_handle h) {
 
 int sort_positions(ptycho_handle h, const float* scan, hipStream_t st) {
     const int total = h->ge.ptheta * h->ge.nscan;
+    // The order depends only on the scan positions.  A caller that knows they have not
+    // changed since the previous call on this handle (option "trust_order") skips the sort.
+    if (h->trust_order && h->order_scan == scan) return PTYCHO_OK;
+    h->order_scan = scan;
     ProfSpan ps(h, K_SORT, st);
     hipLaunchKernelGGL(k_sort_keys, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, scan, h->ge, total,
                        h->keys_a, h->vals_a);
@@ -1907,6 +1913,11 @@ int ptycho_set_option(ptycho_handle h, const char* name, long long value) {
     }
     if (std::strcmp(name, "window") == 0) {
         h->use_window = value != 0;
+        return PTYCHO_OK;
+    }
+    if (std::strcmp(name, "trust_order") == 0) {
+        h->trust_order = value != 0;
+        if (!h->trust_order) h->order_scan = nullptr;
         return PTYCHO_OK;
     }
     if (std::strcmp(name, "team") == 0) {

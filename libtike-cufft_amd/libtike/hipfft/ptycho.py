@@ -163,6 +163,16 @@ class PtychoHIP:
             raise ValueError(f"{name}: shape {tuple(x.shape)} != expected {tuple(shape)}")
         return x if x.is_contiguous() else x.contiguous()
 
+    def _note_scan(self, scan):
+        """Tell the native side whether ``scan`` is the tensor (same storage, same torch
+        version counter) the previous operator call sorted; if so the sort is reused."""
+        key = (scan.data_ptr(), scan._version, tuple(scan.shape))
+        same = getattr(self, "_scan_key", None) == key
+        if same != getattr(self, "_scan_trusted", False):
+            nat.check(nat.set_option(self._h, b"trust_order", int(same)))
+            self._scan_trusted = same
+        self._scan_key = key
+
     # -- operators (ptycho.py:80-123) ---------------------------------------
     def fwd(self, psi, scan, probe):
         """Ptychography transform (FQ)."""
@@ -171,6 +181,7 @@ class PtychoHIP:
         probe = self._operand(probe, torch.complex64, (self.ptheta, self.nprb, self.nprb), "probe")
         farplane = torch.empty((self.ptheta, self.nscan, self.ndet, self.ndet),
                                dtype=torch.complex64, device=psi.device)
+        self._note_scan(scan)
         nat.check(nat.fwd(self._h, _ptr(farplane), _ptr(psi), _ptr(scan), _ptr(probe), _stream()))
         return farplane
 
@@ -182,6 +193,7 @@ class PtychoHIP:
         probe = self._operand(probe, torch.complex64, (self.ptheta, self.nprb, self.nprb), "probe")
         psi = torch.zeros((self.ptheta, self.nz, self.n), dtype=torch.complex64,
                           device=farplane.device)
+        self._note_scan(scan)
         nat.check(nat.adj(self._h, _ptr(psi), _ptr(farplane), _ptr(scan), _ptr(probe), 0, _stream()))
         return psi
 
@@ -193,6 +205,7 @@ class PtychoHIP:
         psi = self._operand(psi, torch.complex64, (self.ptheta, self.nz, self.n), "psi")
         probe = torch.zeros((self.ptheta, self.nprb, self.nprb), dtype=torch.complex64,
                             device=farplane.device)
+        self._note_scan(scan)
         nat.check(nat.adj(self._h, _ptr(psi), _ptr(farplane), _ptr(scan), _ptr(probe), 1, _stream()))
         return probe
 
@@ -425,6 +438,7 @@ class CGPtychoSolver(PtychoHIP):
 
     # -- fused single-mode gaussian loop -------------------------------------------------
     def _cg_fwd_cols(self, slot, obj, scan, prb):
+        self._note_scan(scan)
         nat.check(nat.cg_fwd_cols(self._h, slot, _ptr(obj), _ptr(scan), _ptr(prb), _stream()))
 
     def _fused_line_search(self, data, ab, costs):
