@@ -175,10 +175,23 @@ def main():
     # the dominant kernel against its own operator's compulsory bytes per launch
     dom = kern[dominant]
     dom_bytes = op_bytes / dom["launches_per_step"]
+    # HBM traffic per step from the committed rocprofv3 PMC passes of this same command
+    # (profiles/traffic.json; a live PMC read is not possible from inside the process)
+    traffic, traffic_src = None, None
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+        names = {"k_cols<FWD>": "k_cols_gatherwin<256, 1>", "k_rows<fwd>": "k_rows<256, -1>",
+                 "k_rows<inv>": "k_rows<256, 1>", "k_cols<ADJ_OBJ>": "k_cols_adjwin<256>"}
+        if ndet == 256 and nprb == 256 and nscan == 4096 and all(names.get(k, "") in tj["kernels"] for k in kern):
+            traffic = sum(tj["kernels"][names[k]].get("fetch_bytes_per_launch", 0.0)
+                          + tj["kernels"][names[k]].get("write_bytes_per_launch", 0.0) for k in kern)
+            traffic_src = tj["source"]
+    except Exception:
+        pass
     roofline = {
         "bound": "hbm",
         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-        "traffic": None,
+        "traffic": traffic, "traffic_unit": "HBM bytes per step (fwd+adj pair), PMC", "traffic_source": traffic_src,
         "what": "fwd+adj pair: %.4e algorithmic B per %d-position batch (16*ndet^2 B/pattern "
                 "+ object, probe, scan) / measured ms_per_step" % (pair_bytes, nscan),
         "dominant_kernel": {
