@@ -931,10 +931,11 @@ __global__ __launch_bounds__(256) void k_rows_fused(const RowFusedArgs a) {
         fft.template load<0>(v, j0, [&](int i) { return (ok && i >= a.xa && i < a.xb) ? a.s1[rowoff + i] : zero; });
         fwd_row(v, g1);
         float d[E];
-        if (EP != EP_ACCUM_I && EP != EP_ACCUM_P) {
+        auto load_data = [&]() {
 #pragma unroll
             for (int m = 0; m < E; ++m) d[m] = ok ? a.data[rowoff + j0 + m * T] : 0.0f;
-        }
+        };
+        if (EP == EP_STATS || EP == EP_PROJECT) load_data();
 
         if (EP == EP_STATS) {
 #pragma unroll
@@ -1007,6 +1008,7 @@ __global__ __launch_bounds__(256) void k_rows_fused(const RowFusedArgs a) {
             c32 g2[E];
             fft.template load<0>(v, j0, [&](int i) { return (ok && i >= a.xa && i < a.xb) ? a.s2[rowoff + i] : zero; });
             fwd_row(v, g2);
+            load_data();   // after the second transform: keeps 16 registers free during it
 #pragma unroll
             for (int m = 0; m < E; ++m) {
                 const c32 t1 = g1[m] * s;
