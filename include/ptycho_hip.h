@@ -117,6 +117,16 @@ int ptycho_cg_array_costs(ptycho_handle h, const void* p1, const void* p2, const
                           const void* data, double gamma0, int ncand, double* costs,
                           void* stream);
 
+/* Position correction (ptycho.py:398-403 + 198-207), fused: with the column passes of
+ * fwd(psi, 1) in slot1 and fwd(dpsi, 1) in slot2,
+ *   ptycho_cg_cross   image_product = u1 conj(u2), u2 = u1 + gamma G dpsi (complex64
+ *                     [ptheta][nscan][ndet][ndet], kept for the zoomed DFT); slot2 <- IDFT_x(product)
+ *   ptycho_cg_argmax  IDFT_y of the slot, |.|, first maximum per position as
+ *                     best[p] = (float bits of the value << 32) | (0xffffffff - flat index) */
+int ptycho_cg_cross(ptycho_handle h, int slot1, int slot2, double gamma, void* image_product,
+                    void* stream);
+int ptycho_cg_argmax(ptycho_handle h, int slot, void* best, void* stream);
+
 /* Tuning knobs: "chunk" (positions per launch pair, 0 = default);
  * "window" (1 = LDS overlap-add object adjoint [default], 0 = direct atomics);
  * "trust_order" (1 = the caller vouches that the scan buffer passed to the next calls is the
@@ -132,7 +142,8 @@ int ptycho_set_option(ptycho_handle h, const char* name, long long value);
  * the recorded launches, returns summed milliseconds and launch counts per kernel
  * (index 0 k_cols<FWD>, 1 k_rows<fwd>, 2 k_rows<inv>, 3 k_cols<ADJ_OBJ>,
  * 4 k_cols<ADJ_PRB>, 5 k_cols<PLAIN>, 6 position sort, 7-9 fused CG row passes,
- * 10 k_fwd_team, 11 accumulate row passes, 12 array reductions; n >= 13)
+ * 10 k_fwd_team, 11 accumulate row passes, 12 array reductions, 13 cross row pass,
+ * 14 arg-max column pass; n >= 15)
  * and clears the record.
  * No counterpart in the reference (it has no timing code). */
 int ptycho_profile(ptycho_handle h, int enable);

@@ -851,7 +851,7 @@ __global__ void k_sort_keys(const float* __restrict__ scan, const Geom ge, const
 //                 sum (sqrt|p1 + y^2 p2 + y p3| - sqrt d)^2 for y = gamma0 * 2^-j, j < ncand,
 //                 plus f(p1) -- every trial of line_search_sqr in one pass (ptycho.py:253-281)
 // ---------------------------------------------------------------------------
-enum RowEp { EP_STATS = 1, EP_PROJECT = 2, EP_LINESEARCH = 3, EP_ACCUM_I = 4, EP_ACCUM_P = 5 };
+enum RowEp { EP_STATS = 1, EP_PROJECT = 2, EP_LINESEARCH = 3, EP_ACCUM_I = 4, EP_ACCUM_P = 5, EP_CROSS = 6 };
 constexpr int kMaxCand = 16;
 
 struct RowFusedArgs {
@@ -872,6 +872,7 @@ struct RowFusedArgs {
     float* acc2;         // EP_ACCUM_P: p2
     float* acc3;         // EP_ACCUM_P: p3
     int first;           // 1: overwrite the arrays, 0: add to them
+    c32* ip;             // EP_CROSS: image product u1 * conj(u2), [positions][ndet][ndet]
 };
 
 template <int N, int EP>
@@ -936,6 +937,40 @@ __global__ __launch_bounds__(256) void k_rows_fused(const RowFusedArgs a) {
             for (int m = 0; m < E; ++m) d[m] = ok ? a.data[rowoff + j0 + m * T] : 0.0f;
         };
         if (EP == EP_STATS || EP == EP_PROJECT) load_data();
+        if (EP == EP_CROSS) {
+            // position correction (ptycho.py:398-403,198-204): u1 = G psi, u2 = G(psi + gamma dpsi)
+            // = u1 + gamma G dpsi (ones probe); image product u1 conj(u2) is kept for the zoomed
+            // DFT and its inverse row DFT goes back into the slot (column pass + arg-max follow).
+            c32 g2[E], rr[E];
+            fft.template load<0>(v, j0, [&](int i) { return (ok && i >= a.xa && i < a.xb) ? a.s2[rowoff + i] : zero; });
+            fwd_row(v, g2);
+#pragma unroll
+            for (int m = 0; m < E; ++m) {
+                const c32 u2 = g1[m] + g2[m] * a.gamma0;
+                rr[m] = cmulc(g1[m], u2);
+                if (ok) a.ip[rowoff + j0 + m * T] = rr[m];
+            }
+            F::from_natural(rr, v);
+            fft.template compute_rev<0>(v);
+            if (P::NSTEP > 1) {
+                fft.template store<0>(v, j0, [&](int i, c32 val) { lds[L::at(f, i)] = val; });
+                __syncthreads();
+                fft.template load<1>(v, j0, [&](int i) { return lds[L::at(f, i)]; });
+                if (P::NSTEP > 2) {
+                    __syncthreads();
+                    fft.template compute_rev<1>(v);
+                    fft.template store<1>(v, j0, [&](int i, c32 val) { lds[L::at(f, i)] = val; });
+                    __syncthreads();
+                    fft.template load<2>(v, j0, [&](int i) { return lds[L::at(f, i)]; });
+                }
+                fft.template compute_rev<LAST>(v);
+            }
+            fft.template store<LAST>(v, j0, [&](int i, c32 val) {
+                if (ok) a.out[rowoff + i] = val;
+            });
+            if (P::NSTEP > 1) __syncthreads();
+            continue;
+        }
 
         if (EP == EP_STATS) {
 #pragma unroll
@@ -1031,7 +1066,7 @@ __global__ __launch_bounds__(256) void k_rows_fused(const RowFusedArgs a) {
             }
         }
     }
-    if (EP == EP_ACCUM_I || EP == EP_ACCUM_P) return;
+    if (EP == EP_ACCUM_I || EP == EP_ACCUM_P || EP == EP_CROSS) return;
     // ---- block reduction (float partials -> double), one atomic per value per workgroup
     const int lane = tid & 63, wave = tid >> 6;
 #pragma unroll
@@ -1046,6 +1081,70 @@ __global__ __launch_bounds__(256) void k_rows_fused(const RowFusedArgs a) {
         const double x = red[tid] + red[NACC + tid] + red[2 * NACC + tid] + red[3 * NACC + tid];
         if (EP != EP_LINESEARCH || tid < a.ncand || tid == kMaxCand)
             atomicAdd(a.sums + (EP == EP_LINESEARCH && tid == kMaxCand ? a.ncand : tid), x);
+    }
+}
+
+// Column pass of the coarse cross-correlation with a fused arg-max (ptycho.py:204-207):
+// inverse DFT over y of the slot's tiles, |.|, and per position the first maximum as a packed
+// 64-bit key (value bits << 32 | ~flat index) merged with atomicMax.
+template <int N>
+__global__ __launch_bounds__(ColCfg<N>::NT) void k_cols_argmax(const c32* __restrict__ tiles, const c32* __restrict__ table,
+                                                               unsigned long long* __restrict__ best, const int npos,
+                                                               const int ngroups) {
+    using P = Plan<N>;
+    using F = Fft<P, +1>;
+    constexpr int E = P::E, T = P::T, C = ColCfg<N>::C, NT = ColCfg<N>::NT;
+    constexpr int LAST = P::NSTEP - 1;
+    constexpr int NW = (NT + 63) / 64;
+    __shared__ c32 lds[N * C];
+    __shared__ unsigned long long red[NW];
+    const int tid = threadIdx.x;
+    const int c = tid % C, j0 = tid / C;
+    constexpr int nstrips = N / C;
+    const int strip = blockIdx.x % nstrips, group = blockIdx.x / nstrips;
+    const int x = strip * C + c;
+    F fft;
+    fft.init(j0, table);
+    for (int p = group; p < npos; p += ngroups) {
+        const c32* tile = tiles + (size_t)p * N * N;
+        c32 v[E];
+        fft.template load<0>(v, j0, [&](int i) { return tile[(size_t)i * N + x]; });
+        fft.template compute<0>(v);
+        if (P::NSTEP > 1) {
+            fft.template store<0>(v, j0, [&](int i, c32 val) { lds[i * C + c] = val; });
+            __syncthreads();
+            fft.template load<1>(v, j0, [&](int i) { return lds[i * C + c]; });
+            if (P::NSTEP > 2) {
+                __syncthreads();
+                fft.template compute<1>(v);
+                fft.template store<1>(v, j0, [&](int i, c32 val) { lds[i * C + c] = val; });
+                __syncthreads();
+                fft.template load<2>(v, j0, [&](int i) { return lds[i * C + c]; });
+            }
+            fft.template compute<LAST>(v);
+        }
+        c32 nat[E];
+        F::to_natural(v, nat);
+        unsigned long long key = 0ull;
+#pragma unroll
+        for (int m = 0; m < E; ++m) {
+            const float mag = sqrtf(nat[m].x * nat[m].x + nat[m].y * nat[m].y);
+            const unsigned idx = (unsigned)((j0 + m * T) * N + x);
+            const unsigned long long k2 = ((unsigned long long)__float_as_uint(mag) << 32) | (unsigned long long)(0xffffffffu - idx);
+            key = k2 > key ? k2 : key;
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            const unsigned long long o = __shfl_down(key, off, 64);
+            key = o > key ? o : key;
+        }
+        if ((tid & 63) == 0) red[tid >> 6] = key;
+        __syncthreads();
+        if (tid == 0) {
+            for (int w = 1; w < NW; ++w) key = red[w] > key ? red[w] : key;
+            atomicMax(best + p, key);
+        }
+        __syncthreads();
     }
 }
 
@@ -1363,7 +1462,7 @@ __global__ __launch_bounds__(256) void k_fwd_team(const TeamArgs a) {
 thread_local std::string g_err;
 
 // kernel ids for the in-library profiler (ptycho_profile_read)
-enum { K_COLS_FWD = 0, K_ROWS_FWD = 1, K_ROWS_INV = 2, K_COLS_ADJ_OBJ = 3, K_COLS_ADJ_PRB = 4, K_COLS_PLAIN = 5, K_SORT = 6, K_ROWS_STATS = 7, K_ROWS_PROJECT = 8, K_ROWS_LINESEARCH = 9, K_FWD_TEAM = 10, K_ROWS_ACCUM = 11, K_ARRAY_REDUCE = 12, K_COUNT = 13 };
+enum { K_COLS_FWD = 0, K_ROWS_FWD = 1, K_ROWS_INV = 2, K_COLS_ADJ_OBJ = 3, K_COLS_ADJ_PRB = 4, K_COLS_PLAIN = 5, K_SORT = 6, K_ROWS_STATS = 7, K_ROWS_PROJECT = 8, K_ROWS_LINESEARCH = 9, K_FWD_TEAM = 10, K_ROWS_ACCUM = 11, K_ARRAY_REDUCE = 12, K_ROWS_CROSS = 13, K_COLS_ARGMAX = 14, K_COUNT = 15 };
 
 int fail(int code, const std::string& msg) {
     g_err = msg;
@@ -1744,7 +1843,7 @@ int do_cg_rows(ptycho_handle h, RowFusedArgs a, hipStream_t st) {
     long long nb = (a.nrows + B - 1) / B;
     long long grid = nb < (long long)h->n_cu * 8 ? nb : (long long)h->n_cu * 8;
     {
-        ProfSpan ps(h, EP == EP_STATS ? K_ROWS_STATS : EP == EP_PROJECT ? K_ROWS_PROJECT : EP == EP_LINESEARCH ? K_ROWS_LINESEARCH : K_ROWS_ACCUM, st);
+        ProfSpan ps(h, EP == EP_STATS ? K_ROWS_STATS : EP == EP_PROJECT ? K_ROWS_PROJECT : EP == EP_LINESEARCH ? K_ROWS_LINESEARCH : EP == EP_CROSS ? K_ROWS_CROSS : K_ROWS_ACCUM, st);
         hipLaunchKernelGGL((k_rows_fused<N, EP>), dim3((unsigned)grid), dim3(256), 0, st, a);
     }
     HIP_TRY(hipGetLastError());
@@ -1939,7 +2038,7 @@ int ptycho_profile(ptycho_handle h, int enable) {
 int ptycho_profile_read(ptycho_handle h, double* ms, long long* launches, int n) {
     int rc = check_handle(h);
     if (rc) return rc;
-    if (!ms || !launches || n < K_COUNT) return fail(PTYCHO_ERR_ARG, "need arrays of at least 13 entries");
+    if (!ms || !launches || n < K_COUNT) return fail(PTYCHO_ERR_ARG, "need arrays of at least 15 entries");
     for (int i = 0; i < n; ++i) { ms[i] = 0.0; launches[i] = 0; }
     for (auto& sp : h->spans) {
         HIP_TRY(hipEventSynchronize(sp.b));
@@ -2113,3 +2212,46 @@ int ptycho_fft2(ptycho_handle h, void* dst, const void* src, size_t nbatch, int 
 }
 
 }  // extern "C"
+
+template <int N>
+int do_cg_argmax(ptycho_handle h, int slot, unsigned long long* best, hipStream_t st) {
+    using CC = ColCfg<N>;
+    const int npos = h->ge.ptheta * h->ge.nscan;
+    constexpr int nstrips = N / CC::C;
+    int ng = (h->n_cu * 8) / nstrips;
+    if (ng < 1) ng = 1;
+    if (ng > npos) ng = npos;
+    HIP_TRY(hipMemsetAsync(best, 0, (size_t)npos * sizeof(unsigned long long), st));
+    {
+        ProfSpan ps(h, K_COLS_ARGMAX, st);
+        hipLaunchKernelGGL((k_cols_argmax<N>), dim3((unsigned)(nstrips * ng)), dim3(CC::NT), 0, st,
+                           (const c32*)h->work[slot], (const c32*)h->table, best, npos, ng);
+    }
+    HIP_TRY(hipGetLastError());
+    return PTYCHO_OK;
+}
+
+extern "C" int ptycho_cg_cross(ptycho_handle h, int slot1, int slot2, double gamma, void* image_product, void* stream) {
+    int rc = check_handle(h);
+    if (rc) return rc;
+    if (!image_product) return fail(PTYCHO_ERR_ARG, "null operand");
+    if (h->ge.nprb != h->ge.ndet) {
+        // with a padded probe the zero columns of the slots are not materialised; the row pass masks them
+    }
+    if (slot1 < 0 || slot1 > 1 || slot2 < 0 || slot2 > 1 || !h->work[slot1] || !h->work[slot2])
+        return fail(PTYCHO_ERR_ARG, "work slot is empty");
+    RowFusedArgs a{};
+    a.s1 = h->work[slot1]; a.s2 = h->work[slot2]; a.out = h->work[slot2]; a.ip = (c32*)image_product;
+    a.gamma0 = (float)gamma;
+    hipStream_t st = (hipStream_t)stream;
+    PTY_DISPATCH(h->ge.ndet, (do_cg_rows<NN, EP_CROSS>(h, a, st)));
+}
+
+extern "C" int ptycho_cg_argmax(ptycho_handle h, int slot, void* best, void* stream) {
+    int rc = check_handle(h);
+    if (rc) return rc;
+    if (!best) return fail(PTYCHO_ERR_ARG, "null operand");
+    if (slot < 0 || slot > 1 || !h->work[slot]) return fail(PTYCHO_ERR_ARG, "work slot is empty");
+    hipStream_t st = (hipStream_t)stream;
+    PTY_DISPATCH(h->ge.ndet, (do_cg_argmax<NN>(h, slot, (unsigned long long*)best, st)));
+}

@@ -351,19 +351,10 @@ def _argmax2d(a):
     return torch.stack((flat // w, flat % w), dim=1)
 
 
-def register_translation_batch(op, src_image, target_image, upsample_factor=1,
-                               space="real"):
-    """Batched sub-pixel registration by phase cross-correlation
-    (``ptycho.py:190-248``).  ``op`` supplies the 2-D DFT (own HIP FFT)."""
-    if space.lower() == "fourier":
-        src_freq, target_freq = src_image, target_image
-    elif space.lower() == "real":
-        src_freq = op.fft2(src_image.to(torch.complex64))
-        target_freq = op.fft2(target_image.to(torch.complex64))
-    shape = src_freq.shape
-    image_product = src_freq * target_freq.conj()
-    cross = op.fft2(image_product, inverse=True) / float(shape[1] * shape[2])
-    maxima = _argmax2d(torch.abs(cross))
+def _finish_registration(image_product, maxima, upsample_factor):
+    """Second half of ``register_translation_batch`` (``ptycho.py:209-248``): wrap the
+    whole-pixel maxima, then the zoomed matrix DFT around them."""
+    shape = image_product.shape
     mid = [float(np.fix(s / 2)) for s in shape[1:]]
     shifts = maxima.to(torch.float64)
     shifts[:, 0] = torch.where(shifts[:, 0] > mid[0], shifts[:, 0] - shape[1], shifts[:, 0])
@@ -378,10 +369,26 @@ def register_translation_batch(op, src_image, target_image, upsample_factor=1,
         cross = cross / normalization
         maxima = _argmax2d(torch.abs(cross)).to(torch.float64) - dftshift
         shifts = shifts + maxima / upsample_factor
-    for dim in range(src_freq.ndim):          # reference quirk, ptycho.py:243-245
+    for dim in range(image_product.ndim):          # reference quirk, ptycho.py:243-245
         if shape[dim] == 1:
             shifts[dim] = 0
     return shifts
+
+
+def register_translation_batch(op, src_image, target_image, upsample_factor=1,
+                               space="real"):
+    """Batched sub-pixel registration by phase cross-correlation
+    (``ptycho.py:190-248``).  ``op`` supplies the 2-D DFT (own HIP FFT)."""
+    if space.lower() == "fourier":
+        src_freq, target_freq = src_image, target_image
+    elif space.lower() == "real":
+        src_freq = op.fft2(src_image.to(torch.complex64))
+        target_freq = op.fft2(target_image.to(torch.complex64))
+    shape = src_freq.shape
+    image_product = src_freq * target_freq.conj()
+    cross = op.fft2(image_product, inverse=True) / float(shape[1] * shape[2])
+    maxima = _argmax2d(torch.abs(cross))
+    return _finish_registration(image_product, maxima, upsample_factor)
 
 
 # ---------------------------------------------------------------------------
@@ -440,6 +447,25 @@ class CGPtychoSolver(PtychoHIP):
     def _cg_fwd_cols(self, slot, obj, scan, prb):
         self._note_scan(scan)
         nat.check(nat.cg_fwd_cols(self._h, slot, _ptr(obj), _ptr(scan), _ptr(prb), _stream()))
+
+    def _position_shifts(self, psi, dpsi, gammapsi, scan, probe):
+        """Shifts of ptycho.py:398-403.  Fused form (one angle): column passes of
+        fwd(psi, 1) and fwd(dpsi, 1), one row pass that forms u1 conj(u1 + gamma u2) and its
+        inverse row DFT, one column pass with a fused arg-max; then the zoomed DFT."""
+        ones = probe[:, 0] * 0 + 1
+        if not (self.fused and self.ptheta == 1):
+            tmp1 = self.fwd(psi, scan, ones)[0]
+            tmp2 = self.fwd(psi + gammapsi * dpsi, scan, ones)[0]
+            return register_translation_batch(self, tmp1, tmp2, upsample_factor=100, space="fourier")
+        self._cg_fwd_cols(0, psi, scan, ones)
+        self._cg_fwd_cols(1, dpsi, scan, ones)
+        ip = torch.empty((self.nscan, self.ndet, self.ndet), dtype=torch.complex64, device=psi.device)
+        nat.check(nat.cg_cross(self._h, 0, 1, float(gammapsi), _ptr(ip), _stream()))
+        best = torch.empty(self.nscan, dtype=torch.int64, device=psi.device)
+        nat.check(nat.cg_argmax(self._h, 1, _ptr(best), _stream()))
+        idx = 0xffffffff - (best & 0xffffffff)
+        maxima = torch.stack((idx // self.ndet, idx % self.ndet), dim=1)
+        return _finish_registration(ip, maxima, 100)
 
     def _fused_line_search(self, data, ab, costs):
         """All trials of ``line_search_sqr`` (ptycho.py:253-281) for 16 step lengths per
@@ -502,13 +528,7 @@ class CGPtychoSolver(PtychoHIP):
             gammapsi = 0.5 * self._fused_line_search(data, sums, costs)
 
             if i > 0:                                                       # :398-403
-                ones = probe[:, 0] * 0 + 1
-                tmp1 = self.fwd(psi, scan, ones)[0]
-                tmp2 = self.fwd(psi + gammapsi * dpsi, scan, ones)[0]
-                shifts = register_translation_batch(self, tmp1, tmp2, upsample_factor=100,
-                                                    space="fourier")
-                scan[0, :] += shifts.to(scan.dtype)
-                del tmp1, tmp2
+                scan[0, :] += self._position_shifts(psi, dpsi, gammapsi, scan, probe).to(scan.dtype)
             psi = psi + gammapsi * dpsi
 
             # 2) probe step ------------------------------------------------------------
@@ -616,13 +636,7 @@ class CGPtychoSolver(PtychoHIP):
             gammapsi = 0.5 * self._array_line_search(p1, p2, p3, data, costs)
 
             if i > 0:                                                           # :398-403
-                ones = probe[:, 0] * 0 + 1
-                tmp1 = self.fwd(psi, scan, ones)[0]
-                tmp2 = self.fwd(psi + gammapsi * dpsi, scan, ones)[0]
-                shifts = register_translation_batch(self, tmp1, tmp2, upsample_factor=100,
-                                                    space="fourier")
-                scan[0, :] += shifts.to(scan.dtype)
-                del tmp1, tmp2
+                scan[0, :] += self._position_shifts(psi, dpsi, gammapsi, scan, probe).to(scan.dtype)
             psi = psi + gammapsi * dpsi
 
             # 2) probe step, one mode at a time ------------------------------------------

@@ -28,6 +28,7 @@ class CpuSolver(CGPtychoSolver):
         self.history = []
         self.verbose = False
         self.log_every = 1
+        self.fused = False      # statement-by-statement loop: the operators here are the oracle's
 
     ptheta = property(lambda s: s._sz["ptheta"])
     nz = property(lambda s: s._sz["nz"])
