@@ -105,6 +105,26 @@ def test_fused_multimode_matches_unfused(pt):
     assert np.abs(rf["psi"] - want["psi"]).max() < 2e-4
 
 
+def test_two_angles_per_call_fused_and_unfused(pt):
+    """ptheta = 2: two angular views solved in one call (shared scalars a, b and one joint
+    line search, as in the reference's run); fused kernels vs the torch loop vs the oracle."""
+    p, probe, ora, data = setup()
+    rng = np.random.default_rng(4)
+    scan2 = np.concatenate([p["scan"], p["scan"] + rng.random(p["scan"].shape).astype(np.float32) * 0.4])
+    probe2 = np.concatenate([probe, probe * np.exp(0.3j)]).astype(np.complex64)
+    psi_true = np.concatenate([p["psi"], np.conj(p["psi"])])
+    ora2 = cg.OracleSolver(p["nscan"], 32, 32, 2, p["nz"], p["n"])
+    data2 = (np.abs(ora2.fwd(psi_true, scan2, probe2[:, 0])) ** 2).astype(np.float32)
+    want = ora2.run(data2.copy(), np.ones_like(psi_true), scan2.copy(), probe2.copy(), piter=4, recover_prb=True)
+    for fused in (True, False):
+        with pt.CGPtychoSolver(p["nscan"], 32, 32, 2, p["nz"], p["n"]) as slv:
+            slv.verbose, slv.fused = False, fused
+            got = slv.run_batch(data2.copy(), np.ones_like(psi_true), scan2.copy(), probe2.copy(),
+                                piter=4, recover_prb=True)
+        assert np.abs(got["psi"] - want["psi"]).max() < 2e-4, fused
+        assert np.abs(got["probe"] - want["probe"]).max() < 2e-4 * np.abs(want["probe"]).max(), fused
+
+
 def test_run_batch_streams_angle_partitions(pt):
     """run_batch over several independent angles (prefetch on a copy stream) equals solving
     each angle on its own; angle_shard splits the partitions over ranks without a collective."""
