@@ -229,7 +229,7 @@ def main():
         "value": value, "unit": "patterns/s",
         "n_gpus": ngpu, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "complex64 (f32)", "data": "synthetic",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "%d scan positions/GPU x (%dx%d) detector, complex64, nprb=%d, "
                                "1 probe mode, object %dx%d, raster step %d px + jitter "
                                "(BASELINE.json configs[1])" % (nscan, ndet, ndet, nprb, nz, n, step),

@@ -150,6 +150,37 @@ def test_object_adjoint_any_scan_order(pt, ndet, nprb, ntheta):
         assert np.all(got_f[0, 5] == 0)
 
 
+@pytest.mark.parametrize("case", ["one_position", "all_skipped", "one_pixel_probe", "flush_against_edges", "far_outside"])
+def test_edge_cases(pt, case):
+    rng = np.random.default_rng(3)
+    ndet, nprb, nz, n, nscan = 16, 16, 40, 44, 3
+    scan = np.array([[[3.25, 4.5], [10.0, 20.75], [17.5, 1.125]]], np.float32)
+    if case == "one_position":
+        nscan, scan = 1, scan[:, :1]
+    elif case == "all_skipped":
+        scan = -scan - 1.0
+    elif case == "one_pixel_probe":
+        nprb = 1
+    elif case == "flush_against_edges":      # trunc(pos) + nprb + 1 == size exactly, and pos = 0
+        scan = np.array([[[nz - nprb - 1.0, n - nprb - 1.0], [0.0, 0.0], [nz - nprb - 0.5, 0.25]]], np.float32)
+    elif case == "far_outside":              # beyond the object: every tap reads zero / is dropped
+        scan = np.array([[[1000.0, 3.0], [3.0, 5000.5], [2.0, 2.0]]], np.float32)
+    psi = (rng.standard_normal((1, nz, n)) + 1j * rng.standard_normal((1, nz, n))).astype(np.complex64)
+    prb = (rng.standard_normal((1, nprb, nprb)) + 1j * rng.standard_normal((1, nprb, nprb))).astype(np.complex64)
+    y = (rng.standard_normal((1, nscan, ndet, ndet)) + 1j * rng.standard_normal((1, nscan, ndet, ndet))).astype(np.complex64)
+    with pt.PtychoCuFFT(nscan, nprb, ndet, 1, nz, n) as slv:
+        g = host(slv.fwd(dev(psi), dev(scan), dev(prb)))
+        a = host(slv.adj(dev(y), dev(scan), dev(prb)))
+        b = host(slv.adj_probe(dev(y), dev(scan), dev(psi)))
+    for got, want in ((g, op.fwd(psi, scan, prb, ndet, "double")),
+                      (a, op.adj(y, scan, prb, nz, n, "double")),
+                      (b, op.adj_probe(y, scan, psi, nprb, "double"))):
+        scale = max(np.abs(want).max(), 1e-30)
+        assert np.abs(got - want).max() <= REL_MAX * scale + 1e-30
+    if case == "all_skipped":
+        assert not g.any() and not a.any() and not b.any()
+
+
 def test_fft2_matches_numpy(pt):
     rng = np.random.default_rng(0)
     for ndet in (16, 32, 64, 128, 256, 512, 1024):
