@@ -60,6 +60,7 @@ struct ColArgs {
     Geom ge;
     const int* order;   // processing order: position = order[k] (nullptr: identity)
     int natural_tiles;  // ADJ_*: 1 = src tile of position p is tile p (CG work buffers); 0 = tile k - k_begin
+    int nt;             // bit 2: nontemporal strip stores (FWD); bit 3: nontemporal tile loads (ADJ)
     int k_begin, k_end; // range of k handled by this launch; ADJ_* read scratch tile k - k_begin
     int ngroups;        // position groups; grid = nstrips * ngroups
     int strip0, nstrips;
@@ -73,6 +74,7 @@ struct RowArgs {
     const int* tile_index;   // source tile of local tile j is tile_index[j] (nullptr: j); dst is always local
     int xa, xb;   // columns outside [xa, xb) are read as zero
     int wa, wb;   // only columns in [wa, wb) are written
+    int nt;       // 1: nontemporal loads / stores (streaming data with no reuse)
 };
 
 struct Pos {
@@ -351,7 +353,10 @@ __global__ __launch_bounds__(256) void k_rows(const RowArgs a) {
         const c32* srow = a.src + (size_t)((a.tile_index && ok) ? (long long)a.tile_index[tile] : tile) * N * N + (size_t)(r % N) * N;
         c32* drow = a.dst + (size_t)r * N;
         c32 v[E];
-        fft.template load<0>(v, j0, [&](int i) { return (ok && i >= a.xa && i < a.xb) ? srow[i] : zero; });
+        if (a.nt & 1)
+            fft.template load<0>(v, j0, [&](int i) { return (ok && i >= a.xa && i < a.xb) ? __builtin_nontemporal_load(srow + i) : zero; });
+        else
+            fft.template load<0>(v, j0, [&](int i) { return (ok && i >= a.xa && i < a.xb) ? srow[i] : zero; });
         fft.template compute<0>(v);
         if (P::NSTEP > 1) {
             fft.template store<0>(v, j0, [&](int i, c32 val) { lds[L::at(f, i)] = val; });
@@ -366,9 +371,14 @@ __global__ __launch_bounds__(256) void k_rows(const RowArgs a) {
             }
             fft.template compute<LAST>(v);
         }
-        fft.template store<LAST>(v, j0, [&](int i, c32 val) {
-            if (ok && i >= a.wa && i < a.wb) drow[i] = val;
-        });
+        if (a.nt & 2)
+            fft.template store<LAST>(v, j0, [&](int i, c32 val) {
+                if (ok && i >= a.wa && i < a.wb) __builtin_nontemporal_store(val, drow + i);
+            });
+        else
+            fft.template store<LAST>(v, j0, [&](int i, c32 val) {
+                if (ok && i >= a.wa && i < a.wb) drow[i] = val;
+            });
         if (P::NSTEP > 1) __syncthreads();
     }
 }
@@ -478,7 +488,10 @@ __global__ __launch_bounds__(ColCfg<N>::NT) void k_cols_adjwin(const ColArgs a, 
     c32 v[E];
     if (st.have && st.q.valid) {
         const c32* tile_in = tile_of(st, kb);
-        fft.template load<0>(v, j0, [&](int i) { return tile_in[(size_t)i * N + x]; });
+        if (a.nt & 8)
+            fft.template load<0>(v, j0, [&](int i) { return __builtin_nontemporal_load(tile_in + (size_t)i * N + x); });
+        else
+            fft.template load<0>(v, j0, [&](int i) { return tile_in[(size_t)i * N + x]; });
     }
     for (int k = kb; k < ke; ++k) {
         St nx = decode(k + 1);
@@ -530,7 +543,10 @@ __global__ __launch_bounds__(ColCfg<N>::NT) void k_cols_adjwin(const ColArgs a, 
         // prefetch the next tile while the combine runs
         if (nx.have && nx.q.valid) {
             const c32* tile_in = tile_of(nx, k + 1);
-            fft.template load<0>(v, j0, [&](int i) { return tile_in[(size_t)i * N + x]; });
+            if (a.nt & 8)
+                fft.template load<0>(v, j0, [&](int i) { return __builtin_nontemporal_load(tile_in + (size_t)i * N + x); });
+            else
+                fft.template load<0>(v, j0, [&](int i) { return tile_in[(size_t)i * N + x]; });
         }
         // ---- window bookkeeping (all quantities are workgroup-uniform) -------------------
         const int Xa = q.sx + x0 - ge.pad;   // object column of strip column cc = 0
@@ -795,7 +811,10 @@ __global__ __launch_bounds__(ColCfg<N>::NT) void k_cols_gatherwin(const ColArgs 
         }
         if (MODE == M_FWD) {
             c32* tile_out = a.dst + (size_t)st.p * N * N;
-            fft.template store<LAST>(v, j0, [&](int i, c32 val) { tile_out[(size_t)i * N + x] = val; });
+            if (a.nt & 4)
+                fft.template store<LAST>(v, j0, [&](int i, c32 val) { __builtin_nontemporal_store(val, tile_out + (size_t)i * N + x); });
+            else
+                fft.template store<LAST>(v, j0, [&](int i, c32 val) { tile_out[(size_t)i * N + x] = val; });
             prepare_commit();
             __syncthreads();   // exchange buffer / new window rows visible to everyone
         } else {
@@ -1580,6 +1599,8 @@ int launch_adjwin(ptycho_handle h, ColArgs a, hipStream_t st) {
     if (seglen < 8) seglen = 8;
     if (seglen > kRunMax) seglen = kRunMax;
     nseg = (np + seglen - 1) / seglen;
+    static const int nt_mode_a = std::getenv("PTYCHO_HIP_NT") ? std::atoi(std::getenv("PTYCHO_HIP_NT")) : 0;
+    a.nt = nt_mode_a;
     {
         ProfSpan ps(h, K_COLS_ADJ_OBJ, st);
         hipLaunchKernelGGL((k_cols_adjwin<N>), dim3((unsigned)(a.nstrips * nseg)), dim3(CC::NT), 0, st, a, seglen);
@@ -1599,6 +1620,8 @@ int launch_gatherwin(ptycho_handle h, ColArgs a, hipStream_t st) {
     if (seglen < 8) seglen = 8;
     if (seglen > kRunMax) seglen = kRunMax;
     nseg = (np + seglen - 1) / seglen;
+    static const int nt_mode_g = std::getenv("PTYCHO_HIP_NT") ? std::atoi(std::getenv("PTYCHO_HIP_NT")) : 0;
+    a.nt = nt_mode_g;
     {
         ProfSpan ps(h, MODE == M_FWD ? K_COLS_FWD : K_COLS_ADJ_PRB, st);
         hipLaunchKernelGGL((k_cols_gatherwin<N, MODE>), dim3((unsigned)(a.nstrips * nseg)), dim3(CC::NT), 0, st, a, seglen);
@@ -1613,6 +1636,10 @@ int launch_rows(ptycho_handle h, RowArgs a, hipStream_t st) {
     if (a.nrows <= 0) return PTYCHO_OK;
     long long nb = (a.nrows + B - 1) / B;
     long long grid = nb < (long long)h->n_cu * 8 ? nb : (long long)h->n_cu * 8;
+    // nontemporal row-pass loads and stores: the rows are streamed once (measured 3-4 % on the pair;
+    // nontemporal column-pass accesses made no difference).  PTYCHO_HIP_NT overrides (bit mask).
+    static const int nt_mode = std::getenv("PTYCHO_HIP_NT") ? std::atoi(std::getenv("PTYCHO_HIP_NT")) : 3;
+    a.nt = nt_mode;
     {
         ProfSpan ps(h, DIR < 0 ? K_ROWS_FWD : K_ROWS_INV, st);
         hipLaunchKernelGGL((k_rows<N, DIR>), dim3((unsigned)grid), dim3(256), 0, st, a);
