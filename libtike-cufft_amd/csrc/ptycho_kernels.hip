@@ -725,6 +725,88 @@ __global__ __launch_bounds__(ColCfg<N>::NT) void k_cols_gatherwin(const ColArgs 
     };
 
     __syncthreads();
+    if constexpr (MODE == M_ADJ_PRB) {
+        // Probe adjoint: the window of position k is only needed after its transform, so its
+        // update is issued right after the exchange barrier of k, and the tile of k+1 is
+        // prefetched before the accumulation of k: two barriers per position.
+        auto decode_only = [&](int k) -> St {
+            St st;
+            st.have = k < ke;
+            st.p = 0; st.t = 0; st.Xa = 0; st.q = Pos{0, 0, 0.f, 0.f, false, false};
+            if (!st.have) return st;
+            st.p = rm.p[k - kb];
+            st.t = st.p / ge.nscan;
+            st.q = decode_xy(rm.py[k - kb], rm.px[k - kb], ge);
+            return st;
+        };
+        auto load_tile = [&](c32* v, const St& st, int k) {
+            const c32* tile_in = a.src + (size_t)(a.natural_tiles ? st.p : (k - a.k_begin)) * N * N;
+            fft.template load<0>(v, j0, [&](int i) { return tile_in[(size_t)i * N + x]; });
+        };
+        __syncthreads();   // run metadata visible
+        St st = decode_only(kb);
+        c32 v[E];
+        if (st.have && st.q.valid) load_tile(v, st, kb);
+        for (int k = kb; k < ke; ++k) {
+            St nx = decode_only(k + 1);
+            if (!st.q.valid) {
+                if (nx.have && nx.q.valid) load_tile(v, nx, k + 1);
+                st = nx;
+                continue;
+            }
+            if (st.t != cur_t) {
+                if (cur_t >= 0) flush_probe(cur_t);
+#pragma unroll
+                for (int m = 0; m < E; ++m) pr[m] = zero;
+                cur_t = st.t;
+            }
+            fft.template compute<0>(v);
+            if (P::NSTEP > 1) {
+                fft.template store<0>(v, j0, [&](int i, c32 val) { lds[i * C + c] = val; });
+                __syncthreads();   // also: the accumulation of k-1 is over, the window may move
+            } else {
+                __syncthreads();
+            }
+            const St cur = prepare_issue(k, ke);   // same decode as st, plus the window update
+            if (P::NSTEP > 1) {
+                fft.template load<1>(v, j0, [&](int i) { return lds[i * C + c]; });
+                if (P::NSTEP > 2) {
+                    __syncthreads();
+                    fft.template compute<1>(v);
+                    fft.template store<1>(v, j0, [&](int i, c32 val) { lds[i * C + c] = val; });
+                    __syncthreads();
+                    fft.template load<2>(v, j0, [&](int i) { return lds[i * C + c]; });
+                }
+                fft.template compute<LAST>(v);
+            }
+            c32 nat[E];
+            F::to_natural(v, nat);
+            if (nx.have && nx.q.valid) load_tile(v, nx, k + 1);   // prefetch under the accumulation
+            prepare_commit();
+            __syncthreads();   // window rows of k in place; exchange buffer free
+            const Pos q = cur.q;
+            const float w00 = (1.0f - q.fx) * (1.0f - q.fy), w01 = q.fx * (1.0f - q.fy);
+            const float w10 = (1.0f - q.fx) * q.fy, w11 = q.fx * q.fy;
+            const int colw = cur.Xa - X0 + c;
+            int slot = (q.sy + j0 - ge.pad + 2 * H) % H;
+#pragma unroll
+            for (int m = 0; m < E; ++m) {
+                const int iy = j0 + m * T - ge.pad;
+                const bool ok = col_ok && iy >= 0 && iy < ge.nprb;
+                const int s1 = slot + 1 == H ? 0 : slot + 1;
+                const c32* r0 = win + slot * WC + colw;
+                const c32* r1 = win + s1 * WC + colw;
+                const c32 patch = r0[0] * w00 + r0[1] * w01 + r1[0] * w10 + r1[1] * w11;   // kernels.cu:84-91
+                const c32 term = cmulc(nat[m], patch);
+                pr[m] += ok ? term : zero;
+                slot += T;
+                slot = slot >= H ? slot - H : slot;
+            }
+            st = nx;
+        }
+        if (cur_t >= 0) flush_probe(cur_t);
+        return;
+    }
     St st = prepare(kb, ke);
     __syncthreads();
     for (int k = kb; k < ke; ++k) {
@@ -948,12 +1030,12 @@ __global__ __launch_bounds__(256) void k_rows_fused(const RowFusedArgs a) {
         const bool ok = r < a.nrows;
         const size_t rowoff = (size_t)r * N;
         c32 v[E], g1[E];
-        fft.template load<0>(v, j0, [&](int i) { return (ok && i >= a.xa && i < a.xb) ? a.s1[rowoff + i] : zero; });
+        fft.template load<0>(v, j0, [&](int i) { return (ok && i >= a.xa && i < a.xb) ? __builtin_nontemporal_load(a.s1 + rowoff + i) : zero; });
         fwd_row(v, g1);
         float d[E];
         auto load_data = [&]() {
 #pragma unroll
-            for (int m = 0; m < E; ++m) d[m] = ok ? a.data[rowoff + j0 + m * T] : 0.0f;
+            for (int m = 0; m < E; ++m) d[m] = ok ? __builtin_nontemporal_load(a.data + rowoff + j0 + m * T) : 0.0f;
         };
         if (EP == EP_STATS || EP == EP_PROJECT) load_data();
         if (EP == EP_CROSS) {
@@ -961,13 +1043,13 @@ __global__ __launch_bounds__(256) void k_rows_fused(const RowFusedArgs a) {
             // = u1 + gamma G dpsi (ones probe); image product u1 conj(u2) is kept for the zoomed
             // DFT and its inverse row DFT goes back into the slot (column pass + arg-max follow).
             c32 g2[E], rr[E];
-            fft.template load<0>(v, j0, [&](int i) { return (ok && i >= a.xa && i < a.xb) ? a.s2[rowoff + i] : zero; });
+            fft.template load<0>(v, j0, [&](int i) { return (ok && i >= a.xa && i < a.xb) ? __builtin_nontemporal_load(a.s2 + rowoff + i) : zero; });
             fwd_row(v, g2);
 #pragma unroll
             for (int m = 0; m < E; ++m) {
                 const c32 u2 = g1[m] + g2[m] * a.gamma0;
                 rr[m] = cmulc(g1[m], u2);
-                if (ok) a.ip[rowoff + j0 + m * T] = rr[m];
+                if (ok) __builtin_nontemporal_store(rr[m], a.ip + rowoff + j0 + m * T);
             }
             F::from_natural(rr, v);
             fft.template compute_rev<0>(v);
@@ -985,7 +1067,7 @@ __global__ __launch_bounds__(256) void k_rows_fused(const RowFusedArgs a) {
                 fft.template compute_rev<LAST>(v);
             }
             fft.template store<LAST>(v, j0, [&](int i, c32 val) {
-                if (ok) a.out[rowoff + i] = val;
+                if (ok) __builtin_nontemporal_store(val, a.out + rowoff + i);
             });
             if (P::NSTEP > 1) __syncthreads();
             continue;
@@ -1009,7 +1091,7 @@ __global__ __launch_bounds__(256) void k_rows_fused(const RowFusedArgs a) {
             }
         } else if (EP == EP_ACCUM_P) {
             c32 g2[E];
-            fft.template load<0>(v, j0, [&](int i) { return (ok && i >= a.xa && i < a.xb) ? a.s2[rowoff + i] : zero; });
+            fft.template load<0>(v, j0, [&](int i) { return (ok && i >= a.xa && i < a.xb) ? __builtin_nontemporal_load(a.s2 + rowoff + i) : zero; });
             fwd_row(v, g2);
             if (ok) {
 #pragma unroll
@@ -1055,12 +1137,12 @@ __global__ __launch_bounds__(256) void k_rows_fused(const RowFusedArgs a) {
                 fft.template compute_rev<LAST>(v);
             }
             fft.template store<LAST>(v, j0, [&](int i, c32 val) {
-                if (ok) a.out[rowoff + i] = val;
+                if (ok) __builtin_nontemporal_store(val, a.out + rowoff + i);
             });
             if (P::NSTEP > 1) __syncthreads();
         } else {   // EP_LINESEARCH
             c32 g2[E];
-            fft.template load<0>(v, j0, [&](int i) { return (ok && i >= a.xa && i < a.xb) ? a.s2[rowoff + i] : zero; });
+            fft.template load<0>(v, j0, [&](int i) { return (ok && i >= a.xa && i < a.xb) ? __builtin_nontemporal_load(a.s2 + rowoff + i) : zero; });
             fwd_row(v, g2);
             load_data();   // after the second transform: keeps 16 registers free during it
 #pragma unroll
