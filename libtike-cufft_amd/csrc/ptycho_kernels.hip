@@ -100,6 +100,11 @@ __device__ __forceinline__ Pos decode_pos(const float* __restrict__ scan, int p,
     return decode_xy(scan[2 * (size_t)p], scan[2 * (size_t)p + 1], ge);
 }
 
+// Values that are the same in every lane (read from LDS at a uniform index): moving them to
+// scalar registers lets the address arithmetic that depends on them run on the scalar unit.
+__device__ __forceinline__ int uni_i(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ float uni_f(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
+
 // positions of one run (<= kRunMax), staged in LDS once per workgroup so that the per-position
 // loop has no dependent global loads (order[k] -> scan[p]) on its critical path
 constexpr int kRunMax = 128;
@@ -474,9 +479,9 @@ __global__ __launch_bounds__(ColCfg<N>::NT) void k_cols_adjwin(const ColArgs a, 
         st.have = k < ke;
         st.p = 0; st.t = 0; st.q = Pos{0, 0, 0.f, 0.f, false, false};
         if (!st.have) return st;
-        st.p = rm.p[k - kb];
+        st.p = uni_i(rm.p[k - kb]);
         st.t = st.p / ge.nscan;
-        st.q = decode_xy(rm.py[k - kb], rm.px[k - kb], ge);
+        st.q = decode_xy(uni_f(rm.py[k - kb]), uni_f(rm.px[k - kb]), ge);
         return st;
     };
     auto tile_of = [&](const St& st, int k) {
@@ -674,9 +679,9 @@ __global__ __launch_bounds__(ColCfg<N>::NT) void k_cols_gatherwin(const ColArgs 
         st.p = 0; st.t = 0; st.Xa = 0; st.q = Pos{0, 0, 0.f, 0.f, false, false};
         pre_slot = -1;
         if (!st.have) return st;
-        st.p = rm.p[k - kb];
+        st.p = uni_i(rm.p[k - kb]);
         st.t = st.p / ge.nscan;
-        st.q = decode_xy(rm.py[k - kb], rm.px[k - kb], ge);
+        st.q = decode_xy(uni_f(rm.py[k - kb]), uni_f(rm.px[k - kb]), ge);
         if (!st.q.valid) return st;
         const c32* ft = (MODE == M_FWD ? a.src : a.aux) + (size_t)st.t * ge.nz * ge.n;
         st.Xa = st.q.sx + x0 - ge.pad;
