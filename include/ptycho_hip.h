@@ -104,15 +104,15 @@ int ptycho_cg_linesearch(ptycho_handle h, int slot1, int slot2, const void* data
  *   ptycho_cg_accum_intensity  inten (first ? = : +=) |g|^2 of the slot
  *   ptycho_cg_array_stats      sums += { sum sqrt(inten d), sum inten }
  *   ptycho_cg_project_multi    as ptycho_cg_project with I = inten * (a/b)^2 (slot from the rescaled probe)
- *   ptycho_cg_accum_terms      p1,p2,p3 (first ? = : +=) |t1|^2, |t2|^2, 2 Re(t1 conj t2)
- *   ptycho_cg_array_costs      as ptycho_cg_linesearch on stored p1,p2,p3 */
+ *   ptycho_cg_accum_terms      p1,p2,p3 (first ? = : +=) |t1|^2, |t2|^2, 2 Re(t1 conj t2), t1 = (a/b) g1 if ab
+ *   ptycho_cg_array_costs      as ptycho_cg_linesearch on stored p1,p2,p3, up to 32 step lengths per pass */
 int ptycho_cg_accum_intensity(ptycho_handle h, int slot, void* inten, int first, void* stream);
 int ptycho_cg_array_stats(ptycho_handle h, const void* inten, const void* data, double* sums,
                           void* stream);
 int ptycho_cg_project_multi(ptycho_handle h, int src_slot, int dst_slot, const void* data,
                             const void* inten, const double* ab, double* cost, void* stream);
 int ptycho_cg_accum_terms(ptycho_handle h, int slot1, int slot2, void* p1, void* p2, void* p3,
-                          int first, void* stream);
+                          int first, const double* ab, void* stream);
 int ptycho_cg_array_costs(ptycho_handle h, const void* p1, const void* p2, const void* p3,
                           const void* data, double gamma0, int ncand, double* costs,
                           void* stream);

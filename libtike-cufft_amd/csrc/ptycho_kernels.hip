@@ -1102,9 +1102,10 @@ __global__ __launch_bounds__(256) void k_rows_fused(const RowFusedArgs a) {
 #pragma unroll
                 for (int m = 0; m < E; ++m) {
                     const size_t o = rowoff + j0 + m * T;
-                    const float p1 = g1[m].x * g1[m].x + g1[m].y * g1[m].y;
+                    const c32 t1 = g1[m] * s;
+                    const float p1 = t1.x * t1.x + t1.y * t1.y;
                     const float p2 = g2[m].x * g2[m].x + g2[m].y * g2[m].y;
-                    const float p3 = 2.0f * (g1[m].x * g2[m].x + g1[m].y * g2[m].y);
+                    const float p3 = 2.0f * (t1.x * g2[m].x + t1.y * g2[m].y);
                     a.acc1[o] = a.first ? p1 : a.acc1[o] + p1;
                     a.acc2[o] = a.first ? p2 : a.acc2[o] + p2;
                     a.acc3[o] = a.first ? p3 : a.acc3[o] + p3;
@@ -1257,12 +1258,14 @@ __global__ __launch_bounds__(ColCfg<N>::NT) void k_cols_argmax(const c32* __rest
 // elementwise reductions over stored arrays (multi-mode CG path): no DFT involved
 //   MODE 0: sums += { sum sqrt(I d), sum I }                                   (ptycho.py:342-343)
 //   MODE 1: costs[j] += sum (sqrt|p1 + y_j^2 p2 + y_j p3| - sqrt d)^2, costs[ncand] += f(p1)
+constexpr int kArrCand = 32;   // candidates per pass of the array line search
+
 template <int MODE>
 __global__ __launch_bounds__(256) void k_array_reduce(const float* __restrict__ p1, const float* __restrict__ p2,
                                                       const float* __restrict__ p3, const float* __restrict__ d,
                                                       const long long n, const float gamma0, const int ncand,
                                                       double* __restrict__ sums) {
-    constexpr int NACC = MODE == 0 ? 2 : kMaxCand + 1;
+    constexpr int NACC = MODE == 0 ? 2 : kArrCand + 1;
     __shared__ double red[4 * NACC];
     float acc[NACC];
 #pragma unroll
@@ -1277,10 +1280,10 @@ __global__ __launch_bounds__(256) void k_array_reduce(const float* __restrict__ 
             const float a1 = p1[i], a2 = p2[i], a3 = p3[i];
             const float sd = sqrtf(dd);
             float df = sqrtf(fabsf(a1)) - sd;
-            acc[kMaxCand] += df * df;
+            acc[kArrCand] += df * df;
             float gam = gamma0;
 #pragma unroll
-            for (int j = 0; j < kMaxCand; ++j) {
+            for (int j = 0; j < kArrCand; ++j) {
                 if (j < ncand) {
                     df = sqrtf(fabsf(a1 + (gam * gam) * a2 + gam * a3)) - sd;
                     acc[j] += df * df;
@@ -1300,7 +1303,7 @@ __global__ __launch_bounds__(256) void k_array_reduce(const float* __restrict__ 
     __syncthreads();
     if (tid < NACC) {
         const double x = red[tid] + red[NACC + tid] + red[2 * NACC + tid] + red[3 * NACC + tid];
-        if (MODE == 0 || tid < ncand || tid == kMaxCand) atomicAdd(sums + (MODE == 1 && tid == kMaxCand ? ncand : tid), x);
+        if (MODE == 0 || tid < ncand || tid == kArrCand) atomicAdd(sums + (MODE == 1 && tid == kArrCand ? ncand : tid), x);
     }
 }
 
@@ -2270,7 +2273,8 @@ int ptycho_cg_accum_intensity(ptycho_handle h, int slot, void* inten, int first,
     PTY_DISPATCH(h->ge.ndet, (do_cg_rows<NN, EP_ACCUM_I>(h, a, st)));
 }
 
-int ptycho_cg_accum_terms(ptycho_handle h, int slot1, int slot2, void* p1, void* p2, void* p3, int first, void* stream) {
+int ptycho_cg_accum_terms(ptycho_handle h, int slot1, int slot2, void* p1, void* p2, void* p3, int first,
+                          const double* ab, void* stream) {
     int rc = check_handle(h);
     if (rc) return rc;
     if (!p1 || !p2 || !p3) return fail(PTYCHO_ERR_ARG, "null operand");
@@ -2278,7 +2282,7 @@ int ptycho_cg_accum_terms(ptycho_handle h, int slot1, int slot2, void* p1, void*
         return fail(PTYCHO_ERR_ARG, "work slot is empty");
     RowFusedArgs a{};
     a.s1 = h->work[slot1]; a.s2 = h->work[slot2]; a.acc1 = (float*)p1; a.acc2 = (float*)p2; a.acc3 = (float*)p3;
-    a.first = first;
+    a.first = first; a.ab = ab;
     hipStream_t st = (hipStream_t)stream;
     PTY_DISPATCH(h->ge.ndet, (do_cg_rows<NN, EP_ACCUM_P>(h, a, st)));
 }
@@ -2303,7 +2307,7 @@ int ptycho_cg_array_costs(ptycho_handle h, const void* p1, const void* p2, const
     int rc = check_handle(h);
     if (rc) return rc;
     if (!p1 || !p2 || !p3 || !data || !costs) return fail(PTYCHO_ERR_ARG, "null operand");
-    if (ncand < 1 || ncand > kMaxCand) return fail(PTYCHO_ERR_ARG, "ncand must be in [1, 16]");
+    if (ncand < 1 || ncand > kArrCand) return fail(PTYCHO_ERR_ARG, "ncand must be in [1, 32]");
     const long long n = (long long)h->ge.ptheta * h->ge.nscan * h->ge.ndet * h->ge.ndet;
     hipStream_t st = (hipStream_t)stream;
     {

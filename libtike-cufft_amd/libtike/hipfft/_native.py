@@ -56,7 +56,7 @@ cg_linesearch = _sig("ptycho_cg_linesearch", _i, _vp, _i, _i, _vp, _vp, ctypes.c
 cg_accum_intensity = _sig("ptycho_cg_accum_intensity", _i, _vp, _i, _vp, _i, _vp)
 cg_array_stats = _sig("ptycho_cg_array_stats", _i, _vp, _vp, _vp, _vp, _vp)
 cg_project_multi = _sig("ptycho_cg_project_multi", _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp)
-cg_accum_terms = _sig("ptycho_cg_accum_terms", _i, _vp, _i, _i, _vp, _vp, _vp, _i, _vp)
+cg_accum_terms = _sig("ptycho_cg_accum_terms", _i, _vp, _i, _i, _vp, _vp, _vp, _i, _vp, _vp)
 cg_array_costs = _sig("ptycho_cg_array_costs", _i, _vp, _vp, _vp, _vp, _vp, ctypes.c_double, _i, _vp, _vp)
 cg_cross = _sig("ptycho_cg_cross", _i, _vp, _i, _i, ctypes.c_double, _vp, _vp)
 cg_argmax = _sig("ptycho_cg_argmax", _i, _vp, _i, _vp, _vp)
