@@ -85,6 +85,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
+    if os.environ.get("BENCH_SINGLE_DEVICE") == "1":
+        local = 0          # rehearsal only: several ranks share one GPU (needs BENCH_BACKEND=gloo)
     torch.cuda.set_device(local)
     dist = None
     if world > 1 or os.environ.get("BENCH_FORCE_DIST") == "1":
@@ -94,8 +96,9 @@ def main():
         if "MASTER_ADDR" not in os.environ:
             os.environ["MASTER_ADDR"] = "127.0.0.1"
             os.environ.setdefault("MASTER_PORT", "29517")
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local))
+        backend = os.environ.get("BENCH_BACKEND", "nccl")
+        kw = {"device_id": torch.device("cuda", local)} if backend == "nccl" else {}
+        dist.init_process_group(backend, rank=rank, world_size=world, **kw)
     assert world == args.gpus or world == 1, "launch with torch.distributed.run for --gpus > 1"
     ngpu = world
 
