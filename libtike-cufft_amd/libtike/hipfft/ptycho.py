@@ -316,7 +316,7 @@ def _dy_direction(i, grad, grad0, d):
 # ---------------------------------------------------------------------------
 # position registration (ptycho.py:163-248)
 # ---------------------------------------------------------------------------
-def _upsampled_dft_batch(data, ups, upsample_factor, axis_offsets):
+def _upsampled_dft_batch(data, ups, upsample_factor, axis_offsets, conj=False):
     """Two matrix-multiply DFTs on an ``ups x ups`` window (``ptycho.py:163-188``).
 
     The reference builds a ``[nscan, ups, ndet]`` complex128 kernel per axis,
@@ -325,15 +325,20 @@ def _upsampled_dft_batch(data, ups, upsample_factor, axis_offsets):
     patterns and ``B = exp(+2 pi i off_i f_k)`` a per-pattern phase, so each contraction is
     one dense GEMM with ``A`` after an elementwise phase multiply -- same float64 math,
     no 2.5 GB kernel tensors.  The contraction itself stays torch linear algebra
-    (SURVEY.md section 2, C7)."""
+    (SURVEY.md section 2, C7).
+
+    ``conj=True`` returns ``conj(_upsampled_dft_batch(conj(data), ...))`` -- what the caller
+    at ``ptycho.py:225-228`` actually needs -- by conjugating the (small) phase factors
+    instead of the farplane-sized operand and result."""
     nb, nrow, ncol = data.shape
     dev = data.device
+    sgn = 1.0 if conj else -1.0
     freq = torch.fft.fftfreq(ncol, upsample_factor, dtype=torch.float64, device=dev)
     j = torch.arange(ups, dtype=torch.float64, device=dev)
-    A = torch.exp(-2j * np.pi * (j[:, None] * freq[None, :]).to(torch.complex128))    # [ups, ncol]
+    A = torch.exp(sgn * 2j * np.pi * (j[:, None] * freq[None, :]).to(torch.complex128))    # [ups, ncol]
 
-    def phase(off):                                                                   # [nb, ncol]
-        return torch.exp(2j * np.pi * (off[:, None] * freq[None, :]).to(torch.complex128))
+    def phase(off):                                                                        # [nb, ncol]
+        return torch.exp(-sgn * 2j * np.pi * (off[:, None] * freq[None, :]).to(torch.complex128))
 
     # first axis (columns, k): tmp[i, p, j] = sum_k A[j, k] B1[i, k] data[i, p, k]
     # (complex64 x complex128 promotes inside the multiply: one pass, no separate cast)
@@ -365,8 +370,9 @@ def _finish_registration(image_product, maxima, upsample_factor):
         dftshift = float(np.fix(region / 2.0))
         normalization = shape[1] * shape[2] * upsample_factor ** 2
         offset = dftshift - shifts * upsample_factor
-        cross = _upsampled_dft_batch(image_product.conj(), region, upsample_factor, offset).conj()
-        cross = cross / normalization
+        # = conj(upsampled_dft(conj(image_product))) / normalization of ptycho.py:225-229; the
+        # positive normalisation does not move the arg-max and is skipped
+        cross = _upsampled_dft_batch(image_product, region, upsample_factor, offset, conj=True)
         maxima = _argmax2d(torch.abs(cross)).to(torch.float64) - dftshift
         shifts = shifts + maxima / upsample_factor
     for dim in range(image_product.ndim):          # reference quirk, ptycho.py:243-245
