@@ -1710,6 +1710,14 @@ int launch_gatherwin(ptycho_handle h, ColArgs a, hipStream_t st) {
     if (seglen < 8) seglen = 8;
     if (seglen > kRunMax) seglen = kRunMax;
     nseg = (np + seglen - 1) / seglen;
+    if (const char* e = std::getenv("PTYCHO_HIP_COLSEGS")) {   // experiment knob: fewer, longer runs
+        const int want = std::atoi(e);
+        if (want > 0) {
+            seglen = (np + want - 1) / want;
+            if (seglen > kRunMax) seglen = kRunMax;
+            nseg = (np + seglen - 1) / seglen;
+        }
+    }
     static const int nt_mode_g = std::getenv("PTYCHO_HIP_NT") ? std::atoi(std::getenv("PTYCHO_HIP_NT")) : 0;
     a.nt = nt_mode_g;
     {
