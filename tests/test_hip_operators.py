@@ -181,6 +181,26 @@ def test_edge_cases(pt, case):
         assert not g.any() and not a.any() and not b.any()
 
 
+def test_experimental_paths_give_the_same_results(pt):
+    """Option "pipeline" (two-stream chunk overlap) and "team" (persistent XCD teams) are
+    off by default; when switched on they must still agree with the default path."""
+    p = syn.make_problem(48, 48, 4, 256, 256, seed=2, nz=512, n=512)          # 2304 positions
+    rng = np.random.default_rng(1)
+    y = (rng.standard_normal((1, 2304, 256, 256)) + 1j * rng.standard_normal((1, 2304, 256, 256))).astype(np.complex64)
+    with pt.PtychoCuFFT(2304, 256, 256, 1, 512, 512) as slv:
+        psi, scan, prb, yd = dev(p["psi"]), dev(p["scan"]), dev(p["probe"]), dev(y)
+        ref = [host(slv.fwd(psi, scan, prb)), host(slv.adj(yd, scan, prb)), host(slv.adj_probe(yd, scan, psi))]
+        slv.set_pipeline(True)
+        got = [host(slv.fwd(psi, scan, prb)), host(slv.adj(yd, scan, prb)), host(slv.adj_probe(yd, scan, psi))]
+        slv.set_pipeline(False)
+        slv.set_team(True)
+        team = host(slv.fwd(psi, scan, prb))
+        assert not slv.team_aborted()
+    for a, b in zip(got, ref):
+        assert np.abs(a - b).max() <= 1e-5 * np.abs(b).max()
+    assert np.abs(team - ref[0]).max() <= 1e-5 * np.abs(ref[0]).max()
+
+
 def test_fft2_matches_numpy(pt):
     rng = np.random.default_rng(0)
     for ndet in (16, 32, 64, 128, 256, 512, 1024):
