@@ -1,0 +1,623 @@
+// k_cols_window.hpp -- column pass with the object strip in an LDS window: forward, object adjoint (overlap-add), probe adjoint; sort keys; arg-max pass
+// Part of libptychohip (see ptycho_kernels.hip); included inside its anonymous namespace.
+#pragma once
+
+// ---------------------------------------------------------------------------
+// Object adjoint with on-chip overlap-add (replaces the 8 atomics per probe pixel
+// of kernels.cu:69-81).  A workgroup owns one strip of C probe columns and a
+// contiguous run of positions in SORTED order (same angle, same BX-pixel column
+// bucket, ascending row).  Consecutive positions of such a run overlap almost
+// completely in the object, so their contributions are summed in an LDS window
+// (H rows x WC columns of the object, rows addressed modulo H) and only rows that
+// have slid out of the window are added to global memory, once.  Correctness does
+// not depend on the order: a position that does not fit the current window
+// flushes it and re-anchors.
+// ---------------------------------------------------------------------------
+constexpr int kBucketPx = 4;   // BX: column bucket of the sort key, and window slack
+
+template <int N>
+struct WinCfg {
+    static constexpr int C = ColCfg<N>::C;
+    static constexpr int WC = C + kBucketPx;   // window columns
+    static constexpr int H = N + 8;            // window rows (>= nprb + 1)
+    static constexpr bool fits = (size_t)((N + 2) * (C + 2) + H * WC) * sizeof(c32) <= 160 * 1024;
+};
+
+template <int N>
+__global__ __launch_bounds__(ColCfg<N>::NT) void k_cols_adjwin(const ColArgs a, const int seglen) {
+    using P = Plan<N>;
+    using F = Fft<P, +1>;
+    constexpr int E = P::E, T = P::T, C = ColCfg<N>::C, NT = ColCfg<N>::NT;
+    constexpr int LAST = P::NSTEP - 1;
+    constexpr int WC = WinCfg<N>::WC, H = WinCfg<N>::H;
+    // exchange buffer = T tile, stored with a zero border: element (row i, column c) lives at
+    // (i + 1) * CP + (c + 1); the border is written once and never touched again, which makes
+    // the four bilinear taps of the combine unconditional loads.
+    constexpr int CP = C + 2;
+    __shared__ c32 lds[(N + 2) * CP];
+    __shared__ c32 win[H * WC];
+
+    const int tid = threadIdx.x;
+    const int c = tid % C, j0 = tid / C;
+    const int strip = blockIdx.x % a.nstrips, seg = blockIdx.x / a.nstrips;
+    const int x0 = (a.strip0 + strip) * C;
+    const int x = x0 + c;
+    const Geom ge = a.ge;
+    const int ix = x - ge.pad;
+    const bool col_ok = ix >= 0 && ix < ge.nprb;
+    const float cinv = 1.0f / (float)N;
+    const c32 zero = c32{0.0f, 0.0f};
+    auto at = [&](int i) { return (i + 1) * CP + c + 1; };
+
+    F fft;
+    fft.init(j0, a.table);
+    for (int o = tid; o < H * WC; o += NT) win[o] = zero;
+    for (int o = tid; o < (N + 2) * CP; o += NT) lds[o] = zero;
+
+    c32 pr[E];   // c * probe strip, natural order (row j0 + m*T); zero on padding
+    int cur_t = -1;
+    // window state (uniform across the workgroup)
+    int t_w = -1, X0 = 0, Ybase = 0, Ytop = 0;   // live object rows [Ybase, Ytop), columns [X0, X0+WC)
+
+    auto flush = [&](int ya, int yb) {   // add rows [ya, yb) to the object and clear them
+        if (yb <= ya) return;
+        c32* fo = a.dst + (size_t)t_w * ge.nz * ge.n;
+        const int cnt = (yb - ya) * WC;
+        for (int o = tid; o < cnt; o += NT) {
+            const int Y = ya + o / WC, col = o % WC;
+            const int slot = (Y % H) * WC + col;
+            const c32 v = win[slot];
+            win[slot] = zero;
+            const int X = X0 + col;
+            if ((v.x != 0.0f || v.y != 0.0f) && Y < ge.nz && X >= 0 && X < ge.n) {
+                float* op = reinterpret_cast<float*>(fo + (size_t)Y * ge.n + X);
+                atomicAdd(op, v.x);
+                atomicAdd(op + 1, v.y);
+            }
+        }
+    };
+
+    // combine mapping: item -> (output column cc in [0, C], group of consecutive output rows)
+    constexpr int NRG = NT / (C + 1) > 0 ? NT / (C + 1) : 1;   // row groups
+    constexpr int NITEM = (C + 1) * NRG;
+    const int rpt = (ge.nprb + 1 + NRG - 1) / NRG;              // output rows per item
+
+    const int kb = a.k_begin + seg * seglen;
+    const int ke = kb + seglen < a.k_end ? kb + seglen : a.k_end;
+
+    __shared__ RunMeta rm;
+    load_run(rm, a.order, a.scan, kb, ke, tid);
+    struct St { int p, t; Pos q; bool have; };
+    auto decode = [&](int k) -> St {
+        St st;
+        st.have = k < ke;
+        st.p = 0; st.t = 0; st.q = Pos{0, 0, 0.f, 0.f, false, false};
+        if (!st.have) return st;
+        st.p = uni_i(rm.p[k - kb]);
+        st.t = st.p / ge.nscan;
+        st.q = decode_xy(uni_f(rm.py[k - kb]), uni_f(rm.px[k - kb]), ge);
+        return st;
+    };
+    auto tile_of = [&](const St& st, int k) {
+        return a.src + (size_t)(a.natural_tiles ? st.p : (k - a.k_begin)) * N * N;
+    };
+
+    __syncthreads();
+    St st = decode(kb);
+    c32 v[E];
+    if (st.have && st.q.valid) {
+        const c32* tile_in = tile_of(st, kb);
+        if (a.nt & 8)
+            fft.template load<0>(v, j0, [&](int i) { return __builtin_nontemporal_load(tile_in + (size_t)i * N + x); });
+        else
+            fft.template load<0>(v, j0, [&](int i) { return tile_in[(size_t)i * N + x]; });
+    }
+    for (int k = kb; k < ke; ++k) {
+        St nx = decode(k + 1);
+        if (!st.q.valid) {   // skipped position: nothing to add; fetch the next tile
+            if (nx.have && nx.q.valid) {
+                const c32* tile_in = tile_of(nx, k + 1);
+                fft.template load<0>(v, j0, [&](int i) { return tile_in[(size_t)i * N + x]; });
+            }
+            st = nx;
+            continue;
+        }
+        const Pos q = st.q;
+        if (st.t != cur_t) {
+            const c32* prb = a.aux + (size_t)st.t * ge.nprb * ge.nprb;
+#pragma unroll
+            for (int m = 0; m < E; ++m) {
+                const int iy = j0 + m * T - ge.pad;
+                const bool ok = col_ok && iy >= 0 && iy < ge.nprb;
+                const c32 w = prb[ok ? ((size_t)iy * ge.nprb + ix) : 0];
+                pr[m] = ok ? w * cinv : zero;
+            }
+            cur_t = st.t;
+        }
+        // ---- inverse DFT over y of this strip (tile already in v) ----------------------
+        fft.template compute<0>(v);
+        if (P::NSTEP > 1) {
+            fft.template store<0>(v, j0, [&](int i, c32 val) { lds[at(i)] = val; });
+            __syncthreads();
+            fft.template load<1>(v, j0, [&](int i) { return lds[at(i)]; });
+            if (P::NSTEP > 2) {
+                __syncthreads();
+                fft.template compute<1>(v);
+                fft.template store<1>(v, j0, [&](int i, c32 val) { lds[at(i)] = val; });
+                __syncthreads();
+                fft.template load<2>(v, j0, [&](int i) { return lds[at(i)]; });
+            }
+            fft.template compute<LAST>(v);
+        }
+        // ---- T[y][c] = conj(c * prb) * near, written over the slots this thread just read ----
+        {
+            c32 nat[E];
+            F::to_natural(v, nat);
+#pragma unroll
+            for (int m = 0; m < E; ++m) {
+                const c32 w = pr[m];
+                lds[at(j0 + m * T)] = c32{w.x * nat[m].x + w.y * nat[m].y, w.x * nat[m].y - w.y * nat[m].x};
+            }
+        }
+        // prefetch the next tile while the combine runs
+        if (nx.have && nx.q.valid) {
+            const c32* tile_in = tile_of(nx, k + 1);
+            if (a.nt & 8)
+                fft.template load<0>(v, j0, [&](int i) { return __builtin_nontemporal_load(tile_in + (size_t)i * N + x); });
+            else
+                fft.template load<0>(v, j0, [&](int i) { return tile_in[(size_t)i * N + x]; });
+        }
+        // ---- window bookkeeping (all quantities are workgroup-uniform) -------------------
+        const int Xa = q.sx + x0 - ge.pad;   // object column of strip column cc = 0
+        const bool fitsw = (st.t == t_w) && Xa >= X0 && Xa + C < X0 + WC && q.sy >= Ybase;
+        if (!fitsw) {
+            __syncthreads();
+            flush(Ybase, Ytop);
+            t_w = st.t;
+            X0 = (q.sx / kBucketPx) * kBucketPx + x0 - ge.pad;
+            Ybase = q.sy;
+            Ytop = q.sy;
+        } else if (q.sy > Ybase) {
+            flush(Ybase, q.sy < Ytop ? q.sy : Ytop);   // rows below q.sy: disjoint from this combine
+            Ybase = q.sy;
+            if (Ytop < Ybase) Ytop = Ybase;
+        }
+        if (Ytop < q.sy + ge.nprb + 1) Ytop = q.sy + ge.nprb + 1;
+        __syncthreads();   // T tile complete (and, after a re-anchor, the window is clean)
+        // ---- 4-tap bilinear combine (kernels.cu:73-80) into the window -------------------
+        for (int item = tid; item < NITEM; item += NT) {
+            const int cc = item % (C + 1), rg = item / (C + 1);
+            const int ixo = x0 - ge.pad + cc;                     // probe column of tap (., 0)
+            if (ixo < 0 || ixo > ge.nprb) continue;
+            const float w00 = (1.0f - q.fx) * (1.0f - q.fy), w01 = q.fx * (1.0f - q.fy);
+            const float w10 = (1.0f - q.fx) * q.fy, w11 = q.fx * q.fy;
+            const int y0 = rg * rpt;
+            int y1 = y0 + rpt;
+            if (y1 > ge.nprb + 1) y1 = ge.nprb + 1;
+            if (y0 >= y1) continue;
+            // padded tile: T[y][cc] at (y + 1) * CP + cc + 1 and T[y][cc - 1] at (y + 1) * CP + cc
+            const c32* tp = lds + (y0 + ge.pad) * CP + cc;        // row y - 1 = yy + pad - 1
+            c32 up0 = tp[1], up1 = tp[0];                         // T[y-1][cc], T[y-1][cc-1]
+            int slot = (q.sy + y0) % H;
+            const int colw = Xa - X0 + cc;
+            for (int yy = y0; yy < y1; ++yy) {
+                tp += CP;
+                const c32 t00 = tp[1], t01 = tp[0];
+                win[slot * WC + colw] += t00 * w00 + t01 * w01 + up0 * w10 + up1 * w11;
+                up0 = t00; up1 = t01;
+                slot = slot + 1 == H ? 0 : slot + 1;
+            }
+        }
+        __syncthreads();   // combine done: the tile may be overwritten by the next position
+        st = nx;
+    }
+    __syncthreads();
+    flush(Ybase, Ytop);
+}
+
+// ---------------------------------------------------------------------------
+// Forward operator / probe adjoint with the object strip cached in LDS.
+// Same run structure as k_cols_adjwin: a workgroup owns C probe columns and a
+// contiguous run of SORTED positions; the object rows it needs slide by a few
+// pixels from one position to the next, so only the new rows are fetched from
+// global memory (the reference re-reads four taps per probe pixel per position,
+// kernels.cu:97-104 / :84-91).  Out-of-object taps are stored as zeros, so no
+// separate edge path exists.  The hot loop is branch free: padding pixels are
+// masked by a zero probe value (window is zero-initialised, so stale rows are finite).
+//   M_FWD     : v = (c*prb) * bilerp(window)  -> DFT over y -> strip of g
+//   M_ADJ_PRB : IDFT over y of the scratch strip; acc += near * conj(bilerp(window))
+// ---------------------------------------------------------------------------
+template <int N, int MODE>
+__global__ __launch_bounds__(ColCfg<N>::NT) void k_cols_gatherwin(const ColArgs a, const int seglen) {
+    using P = Plan<N>;
+    constexpr int DIR = (MODE == M_FWD) ? -1 : +1;
+    using F = Fft<P, DIR>;
+    constexpr int E = P::E, T = P::T, C = ColCfg<N>::C, NT = ColCfg<N>::NT;
+    constexpr int LAST = P::NSTEP - 1;
+    constexpr int WC = WinCfg<N>::WC, H = WinCfg<N>::H;
+    constexpr int R0 = P::radix(0), RL = P::radix(LAST), NsL = P::ns(LAST);
+    __shared__ c32 lds[N * C];
+    __shared__ c32 win[H * WC];
+
+    const int tid = threadIdx.x;
+    const int c = tid % C, j0 = tid / C;
+    const int strip = blockIdx.x % a.nstrips, seg = blockIdx.x / a.nstrips;
+    const int x0 = (a.strip0 + strip) * C;
+    const int x = x0 + c;
+    const Geom ge = a.ge;
+    const int ix = x - ge.pad;
+    const bool col_ok = ix >= 0 && ix < ge.nprb;
+    const float cinv = 1.0f / (float)N;
+    const c32 zero = c32{0.0f, 0.0f};
+
+    F fft;
+    fft.init(j0, a.table);
+    for (int o = tid; o < H * WC; o += NT) win[o] = zero;
+
+    // FWD: c * probe strip in step-0 slot order (zero on padding -> masks the gather);
+    // ADJ_PRB: gradient accumulators in natural order m (row j0 + m*T)
+    c32 pr[E];
+    int cur_t = -1;
+    int t_w = -1, X0 = 0, Ylo = 0, Yhi = 0;   // cached object rows [Ylo, Yhi), columns [X0, X0+WC)
+
+    auto flush_probe = [&](int t) {
+#pragma unroll
+        for (int m = 0; m < E; ++m) {
+            const int iy = j0 + m * T - ge.pad;
+            if (col_ok && iy >= 0 && iy < ge.nprb) {
+                float* o = reinterpret_cast<float*>(a.dst + ((size_t)t * ge.nprb + iy) * ge.nprb + ix);
+                const c32 sacc = pr[m] * cinv;
+                atomicAdd(o, sacc.x);
+                atomicAdd(o + 1, sacc.y);
+            }
+        }
+    };
+
+    const int kb = a.k_begin + seg * seglen;
+    const int ke = kb + seglen < a.k_end ? kb + seglen : a.k_end;
+    __shared__ RunMeta rm;
+    load_run(rm, a.order, a.scan, kb, ke, tid);
+
+    struct St { int p, t, Xa; Pos q; bool have; };
+    // Window update for position k, split so that the global loads of the rows that slide in
+    // overlap the second half of the previous position's transform:
+    //   prepare_issue  decodes k (from LDS), slides / re-anchors the window (workgroup-uniform
+    //                  bookkeeping) and starts this thread's load of one new element;
+    //   prepare_commit stores it to the window.  A re-anchor (more new elements than threads)
+    //                  is loaded in place by prepare_issue.
+    c32 pre_val = zero;
+    int pre_slot = -1;
+    auto prepare_issue = [&](int k, int kend) -> St {
+        St st;
+        st.have = k < kend;
+        st.p = 0; st.t = 0; st.Xa = 0; st.q = Pos{0, 0, 0.f, 0.f, false, false};
+        pre_slot = -1;
+        if (!st.have) return st;
+        st.p = uni_i(rm.p[k - kb]);
+        st.t = st.p / ge.nscan;
+        st.q = decode_xy(uni_f(rm.py[k - kb]), uni_f(rm.px[k - kb]), ge);
+        if (!st.q.valid) return st;
+        const c32* ft = (MODE == M_FWD ? a.src : a.aux) + (size_t)st.t * ge.nz * ge.n;
+        st.Xa = st.q.sx + x0 - ge.pad;
+        const int Ra = st.q.sy, Rb = st.q.sy + ge.nprb + 1;
+        const bool colfit = (st.t == t_w) && st.Xa >= X0 && st.Xa + C < X0 + WC;
+        if (!colfit) {
+            t_w = st.t;
+            X0 = (st.q.sx / kBucketPx) * kBucketPx + x0 - ge.pad;
+            Ylo = Ra; Yhi = Ra;
+        } else if (Ra < Ylo || Ra > Yhi) {
+            Ylo = Ra; Yhi = Ra;
+        } else {
+            Ylo = Ra;
+        }
+        if (Rb > Yhi) {
+            const int cnt = (Rb - Yhi) * WC;
+            if (cnt <= NT) {
+                if (tid < cnt) {
+                    const int Y = Yhi + tid / WC, col = tid % WC;
+                    const int X = X0 + col;
+                    const bool inb = Y < ge.nz && X >= 0 && X < ge.n;
+                    const c32 val = ft[inb ? ((size_t)Y * ge.n + X) : 0];
+                    pre_val = inb ? val : zero;
+                    pre_slot = (Y % H) * WC + col;
+                }
+            } else {
+                for (int o = tid; o < cnt; o += NT) {
+                    const int Y = Yhi + o / WC, col = o % WC;
+                    const int X = X0 + col;
+                    const bool inb = Y < ge.nz && X >= 0 && X < ge.n;
+                    const c32 val = ft[inb ? ((size_t)Y * ge.n + X) : 0];
+                    win[(Y % H) * WC + col] = inb ? val : zero;
+                }
+            }
+            Yhi = Rb;
+        }
+        return st;
+    };
+    auto prepare_commit = [&]() {
+        if (pre_slot >= 0) win[pre_slot] = pre_val;
+    };
+    auto prepare = [&](int k, int kend) -> St {
+        St st = prepare_issue(k, kend);
+        prepare_commit();
+        return st;
+    };
+
+    __syncthreads();
+    if constexpr (MODE == M_ADJ_PRB) {
+        // Probe adjoint: the window of position k is only needed after its transform, so its
+        // update is issued right after the exchange barrier of k, and the tile of k+1 is
+        // prefetched before the accumulation of k: two barriers per position.
+        auto decode_only = [&](int k) -> St {
+            St st;
+            st.have = k < ke;
+            st.p = 0; st.t = 0; st.Xa = 0; st.q = Pos{0, 0, 0.f, 0.f, false, false};
+            if (!st.have) return st;
+            st.p = rm.p[k - kb];
+            st.t = st.p / ge.nscan;
+            st.q = decode_xy(rm.py[k - kb], rm.px[k - kb], ge);
+            return st;
+        };
+        auto load_tile = [&](c32* v, const St& st, int k) {
+            const c32* tile_in = a.src + (size_t)(a.natural_tiles ? st.p : (k - a.k_begin)) * N * N;
+            fft.template load<0>(v, j0, [&](int i) { return tile_in[(size_t)i * N + x]; });
+        };
+        __syncthreads();   // run metadata visible
+        St st = decode_only(kb);
+        c32 v[E];
+        if (st.have && st.q.valid) load_tile(v, st, kb);
+        for (int k = kb; k < ke; ++k) {
+            St nx = decode_only(k + 1);
+            if (!st.q.valid) {
+                if (nx.have && nx.q.valid) load_tile(v, nx, k + 1);
+                st = nx;
+                continue;
+            }
+            if (st.t != cur_t) {
+                if (cur_t >= 0) flush_probe(cur_t);
+#pragma unroll
+                for (int m = 0; m < E; ++m) pr[m] = zero;
+                cur_t = st.t;
+            }
+            fft.template compute<0>(v);
+            if (P::NSTEP > 1) {
+                fft.template store<0>(v, j0, [&](int i, c32 val) { lds[i * C + c] = val; });
+                __syncthreads();   // also: the accumulation of k-1 is over, the window may move
+            } else {
+                __syncthreads();
+            }
+            const St cur = prepare_issue(k, ke);   // same decode as st, plus the window update
+            if (P::NSTEP > 1) {
+                fft.template load<1>(v, j0, [&](int i) { return lds[i * C + c]; });
+                if (P::NSTEP > 2) {
+                    __syncthreads();
+                    fft.template compute<1>(v);
+                    fft.template store<1>(v, j0, [&](int i, c32 val) { lds[i * C + c] = val; });
+                    __syncthreads();
+                    fft.template load<2>(v, j0, [&](int i) { return lds[i * C + c]; });
+                }
+                fft.template compute<LAST>(v);
+            }
+            c32 nat[E];
+            F::to_natural(v, nat);
+            if (nx.have && nx.q.valid) load_tile(v, nx, k + 1);   // prefetch under the accumulation
+            prepare_commit();
+            __syncthreads();   // window rows of k in place; exchange buffer free
+            const Pos q = cur.q;
+            const float w00 = (1.0f - q.fx) * (1.0f - q.fy), w01 = q.fx * (1.0f - q.fy);
+            const float w10 = (1.0f - q.fx) * q.fy, w11 = q.fx * q.fy;
+            const int colw = cur.Xa - X0 + c;
+            int slot = (q.sy + j0 - ge.pad + 2 * H) % H;
+#pragma unroll
+            for (int m = 0; m < E; ++m) {
+                const int iy = j0 + m * T - ge.pad;
+                const bool ok = col_ok && iy >= 0 && iy < ge.nprb;
+                const int s1 = slot + 1 == H ? 0 : slot + 1;
+                const c32* r0 = win + slot * WC + colw;
+                const c32* r1 = win + s1 * WC + colw;
+                const c32 patch = r0[0] * w00 + r0[1] * w01 + r1[0] * w10 + r1[1] * w11;   // kernels.cu:84-91
+                const c32 term = cmulc(nat[m], patch);
+                pr[m] += ok ? term : zero;
+                slot += T;
+                slot = slot >= H ? slot - H : slot;
+            }
+            st = nx;
+        }
+        if (cur_t >= 0) flush_probe(cur_t);
+        return;
+    }
+    St st = prepare(kb, ke);
+    __syncthreads();
+    for (int k = kb; k < ke; ++k) {
+        if (MODE == M_FWD && st.t != cur_t) {
+            const c32* prb = a.aux + (size_t)st.t * ge.nprb * ge.nprb;
+#pragma unroll
+            for (int b = 0; b < E / R0; ++b)
+#pragma unroll
+                for (int tt = 0; tt < R0; ++tt) {
+                    const int iy = j0 + b * T + tt * (N / R0) - ge.pad;
+                    const bool ok = col_ok && iy >= 0 && iy < ge.nprb;
+                    const c32 w = prb[ok ? ((size_t)iy * ge.nprb + ix) : 0];
+                    pr[b * R0 + tt] = ok ? w * cinv : zero;
+                }
+            cur_t = st.t;
+        }
+        if (MODE == M_ADJ_PRB && st.q.valid && st.t != cur_t) {
+            if (cur_t >= 0) flush_probe(cur_t);
+#pragma unroll
+            for (int m = 0; m < E; ++m) pr[m] = zero;
+            cur_t = st.t;
+        }
+        if (!st.q.valid) {
+            if (MODE == M_FWD) {   // skipped position: exact zeros (memset of ptychofft.cu:69)
+                c32* tile_out = a.dst + (size_t)st.p * N * N;
+#pragma unroll
+                for (int m = 0; m < E; ++m) tile_out[(size_t)(j0 + m * T) * N + x] = zero;
+            }
+            __syncthreads();
+            st = prepare(k + 1, ke);
+            __syncthreads();
+            continue;
+        }
+        const Pos q = st.q;
+        const float w00 = (1.0f - q.fx) * (1.0f - q.fy), w01 = q.fx * (1.0f - q.fy);
+        const float w10 = (1.0f - q.fx) * q.fy, w11 = q.fx * q.fy;
+        // bilinear patch value of natural element m (row iy = j0 + m*T - pad); rows advance by T
+        // in the window, modulo H, without a division per element.  Padding rows read stale but
+        // finite window rows and are masked by the zero probe value / the select below.
+        const int colw = st.Xa - X0 + c;
+        int slot0 = (q.sy + j0 - ge.pad + 2 * H) % H;
+        auto patch_at = [&](int slot) {
+            const int s1 = slot + 1 == H ? 0 : slot + 1;
+            const c32* r0 = win + slot * WC + colw;
+            const c32* r1 = win + s1 * WC + colw;
+            return r0[0] * w00 + r0[1] * w01 + r1[0] * w10 + r1[1] * w11;   // kernels.cu:97-104
+        };
+
+        c32 v[E];
+        if (MODE == M_FWD) {
+            c32 nat[E];
+            int slot = slot0;
+#pragma unroll
+            for (int m = 0; m < E; ++m) {
+                nat[m] = patch_at(slot);
+                slot += T;
+                slot = slot >= H ? slot - H : slot;
+            }
+            F::from_natural(nat, v);
+#pragma unroll
+            for (int s2 = 0; s2 < E; ++s2) v[s2] = cmul(pr[s2], v[s2]);
+        } else {
+            const c32* tile_in = a.src + (size_t)(a.natural_tiles ? st.p : (k - a.k_begin)) * N * N;
+            fft.template load<0>(v, j0, [&](int i) { return tile_in[(size_t)i * N + x]; });
+        }
+        fft.template compute<0>(v);
+        St nx;
+        if (P::NSTEP > 1) {
+            fft.template store<0>(v, j0, [&](int i, c32 val) { lds[i * C + c] = val; });
+            __syncthreads();
+            if (MODE == M_FWD) nx = prepare_issue(k + 1, ke);   // window of k is no longer read
+            fft.template load<1>(v, j0, [&](int i) { return lds[i * C + c]; });
+            if (P::NSTEP > 2) {
+                __syncthreads();
+                fft.template compute<1>(v);
+                fft.template store<1>(v, j0, [&](int i, c32 val) { lds[i * C + c] = val; });
+                __syncthreads();
+                fft.template load<2>(v, j0, [&](int i) { return lds[i * C + c]; });
+            }
+            fft.template compute<LAST>(v);
+        } else if (MODE == M_FWD) {
+            __syncthreads();
+            nx = prepare_issue(k + 1, ke);
+        }
+        if (MODE == M_FWD) {
+            c32* tile_out = a.dst + (size_t)st.p * N * N;
+            if (a.nt & 4)
+                fft.template store<LAST>(v, j0, [&](int i, c32 val) { __builtin_nontemporal_store(val, tile_out + (size_t)i * N + x); });
+            else
+                fft.template store<LAST>(v, j0, [&](int i, c32 val) { tile_out[(size_t)i * N + x] = val; });
+            prepare_commit();
+            __syncthreads();   // exchange buffer / new window rows visible to everyone
+        } else {
+            c32 nat[E];
+            F::to_natural(v, nat);
+            int slot = slot0;
+#pragma unroll
+            for (int m = 0; m < E; ++m) {
+                const int iy = j0 + m * T - ge.pad;
+                const bool ok = col_ok && iy >= 0 && iy < ge.nprb;
+                const c32 term = cmulc(nat[m], patch_at(slot));
+                pr[m] += ok ? term : zero;
+                slot += T;
+                slot = slot >= H ? slot - H : slot;
+            }
+            __syncthreads();   // everyone is done with the window of k and the exchange buffer
+            nx = prepare(k + 1, ke);
+            __syncthreads();
+        }
+        st = nx;
+    }
+    if (MODE == M_ADJ_PRB && cur_t >= 0) flush_probe(cur_t);
+}
+
+// sort key of one position: angle | column bucket | row; skipped positions last
+__global__ void k_sort_keys(const float* __restrict__ scan, const Geom ge, const int total,
+                            unsigned long long* __restrict__ keys, int* __restrict__ vals) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= total) return;
+    const Pos q = decode_pos(scan, p, ge);
+    unsigned long long key = ~0ull;
+    if (q.valid) {
+        const unsigned long long t = (unsigned long long)(p / ge.nscan);
+        unsigned long long bx = (unsigned long long)(q.sx / kBucketPx), sy = (unsigned long long)q.sy;
+        if (bx > 0x3fffffull) bx = 0x3fffffull;
+        if (sy > 0x3fffffull) sy = 0x3fffffull;
+        key = (t << 44) | (bx << 22) | sy;
+    }
+    keys[p] = key;
+    vals[p] = p;
+}
+
+// Column pass of the coarse cross-correlation with a fused arg-max (ptycho.py:204-207):
+// inverse DFT over y of the slot's tiles, |.|, and per position the first maximum as a packed
+// 64-bit key (value bits << 32 | ~flat index) merged with atomicMax.
+template <int N>
+__global__ __launch_bounds__(ColCfg<N>::NT) void k_cols_argmax(const c32* __restrict__ tiles, const c32* __restrict__ table,
+                                                               unsigned long long* __restrict__ best, const int npos,
+                                                               const int ngroups) {
+    using P = Plan<N>;
+    using F = Fft<P, +1>;
+    constexpr int E = P::E, T = P::T, C = ColCfg<N>::C, NT = ColCfg<N>::NT;
+    constexpr int LAST = P::NSTEP - 1;
+    constexpr int NW = (NT + 63) / 64;
+    __shared__ c32 lds[N * C];
+    __shared__ unsigned long long red[NW];
+    const int tid = threadIdx.x;
+    const int c = tid % C, j0 = tid / C;
+    constexpr int nstrips = N / C;
+    const int strip = blockIdx.x % nstrips, group = blockIdx.x / nstrips;
+    const int x = strip * C + c;
+    F fft;
+    fft.init(j0, table);
+    for (int p = group; p < npos; p += ngroups) {
+        const c32* tile = tiles + (size_t)p * N * N;
+        c32 v[E];
+        fft.template load<0>(v, j0, [&](int i) { return tile[(size_t)i * N + x]; });
+        fft.template compute<0>(v);
+        if (P::NSTEP > 1) {
+            fft.template store<0>(v, j0, [&](int i, c32 val) { lds[i * C + c] = val; });
+            __syncthreads();
+            fft.template load<1>(v, j0, [&](int i) { return lds[i * C + c]; });
+            if (P::NSTEP > 2) {
+                __syncthreads();
+                fft.template compute<1>(v);
+                fft.template store<1>(v, j0, [&](int i, c32 val) { lds[i * C + c] = val; });
+                __syncthreads();
+                fft.template load<2>(v, j0, [&](int i) { return lds[i * C + c]; });
+            }
+            fft.template compute<LAST>(v);
+        }
+        c32 nat[E];
+        F::to_natural(v, nat);
+        unsigned long long key = 0ull;
+#pragma unroll
+        for (int m = 0; m < E; ++m) {
+            const float mag = sqrtf(nat[m].x * nat[m].x + nat[m].y * nat[m].y);
+            const unsigned idx = (unsigned)((j0 + m * T) * N + x);
+            const unsigned long long k2 = ((unsigned long long)__float_as_uint(mag) << 32) | (unsigned long long)(0xffffffffu - idx);
+            key = k2 > key ? k2 : key;
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            const unsigned long long o = __shfl_down(key, off, 64);
+            key = o > key ? o : key;
+        }
+        if ((tid & 63) == 0) red[tid >> 6] = key;
+        __syncthreads();
+        if (tid == 0) {
+            for (int w = 1; w < NW; ++w) key = red[w] > key ? red[w] : key;
+            atomicMax(best + p, key);
+        }
+        __syncthreads();
+    }
+}

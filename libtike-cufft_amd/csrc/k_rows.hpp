@@ -1,0 +1,359 @@
+// k_rows.hpp -- row pass (DFT over x) and its CG-fused variants, array reductions
+// Part of libptychohip (see ptycho_kernels.hip); included inside its anonymous namespace.
+#pragma once
+
+// ---------------------------------------------------------------------------
+// Row pass: DFT over x of contiguous rows, B = 256/T rows per workgroup step.
+// ---------------------------------------------------------------------------
+template <int N, int DIR>
+__global__ __launch_bounds__(256) void k_rows(const RowArgs a) {
+    using P = Plan<N>;
+    using F = Fft<P, DIR>;
+    using L = RowLds<N>;
+    constexpr int E = P::E, T = P::T, B = 256 / T;
+    constexpr int LAST = P::NSTEP - 1;
+    __shared__ c32 lds[P::NSTEP > 1 ? B * L::FS : 1];
+
+    const int tid = threadIdx.x;
+    const int f = tid / T, j0 = tid % T;
+    F fft;
+    fft.init(j0, a.table);
+    const c32 zero = c32{0.0f, 0.0f};
+    const long long nb = (a.nrows + B - 1) / B;
+    for (long long batch = blockIdx.x; batch < nb; batch += gridDim.x) {
+        const long long r = batch * B + f;
+        const bool ok = r < a.nrows;
+        const long long tile = r / N;
+        const c32* srow = a.src + (size_t)((a.tile_index && ok) ? (long long)a.tile_index[tile] : tile) * N * N + (size_t)(r % N) * N;
+        c32* drow = a.dst + ((a.dst_indexed && a.tile_index && ok)
+                                 ? (size_t)a.tile_index[tile] * N * N + (size_t)(r % N) * N
+                                 : (size_t)r * N);
+        c32 v[E];
+        if (a.nt & 1)
+            fft.template load<0>(v, j0, [&](int i) { return (ok && i >= a.xa && i < a.xb) ? __builtin_nontemporal_load(srow + i) : zero; });
+        else
+            fft.template load<0>(v, j0, [&](int i) { return (ok && i >= a.xa && i < a.xb) ? srow[i] : zero; });
+        fft.template compute<0>(v);
+        if (P::NSTEP > 1) {
+            fft.template store<0>(v, j0, [&](int i, c32 val) { lds[L::at(f, i)] = val; });
+            __syncthreads();
+            fft.template load<1>(v, j0, [&](int i) { return lds[L::at(f, i)]; });
+            if (P::NSTEP > 2) {
+                __syncthreads();
+                fft.template compute<1>(v);
+                fft.template store<1>(v, j0, [&](int i, c32 val) { lds[L::at(f, i)] = val; });
+                __syncthreads();
+                fft.template load<2>(v, j0, [&](int i) { return lds[L::at(f, i)]; });
+            }
+            fft.template compute<LAST>(v);
+        }
+        if (a.nt & 2)
+            fft.template store<LAST>(v, j0, [&](int i, c32 val) {
+                if (ok && i >= a.wa && i < a.wb) __builtin_nontemporal_store(val, drow + i);
+            });
+        else
+            fft.template store<LAST>(v, j0, [&](int i, c32 val) {
+                if (ok && i >= a.wa && i < a.wb) drow[i] = val;
+            });
+        if (P::NSTEP > 1) __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Row pass fused with the elementwise stages of the CG loop
+// (src/libtike/cufft/ptycho.py:325-393 launches each of them as separate CuPy
+// kernels over farplane-sized temporaries).  Input rows are column-pass
+// intermediates (DFT over y done); the farplane exists only in registers.
+//   EP_STATS      I = |g|^2 ; sums += [sum sqrt(I d), sum I]             (ptycho.py:330-343)
+//   EP_PROJECT    fpsi = (g s)(1/s'), I' = I s^2,
+//                 r = fpsi - sqrt(d) fpsi / (sqrt(I') + 1e-32), cost += (sqrt I' - sqrt d)^2,
+//                 out row = IDFT_x(r)                                    (ptycho.py:344-356, 310)
+//   EP_LINESEARCH t1 = s g1, t2 = g2: p1,p2,p3 (ptycho.py:383-391) and the cost
+//                 sum (sqrt|p1 + y^2 p2 + y p3| - sqrt d)^2 for y = gamma0 * 2^-j, j < ncand,
+//                 plus f(p1) -- every trial of line_search_sqr in one pass (ptycho.py:253-281)
+// ---------------------------------------------------------------------------
+enum RowEp { EP_STATS = 1, EP_PROJECT = 2, EP_LINESEARCH = 3, EP_ACCUM_I = 4, EP_ACCUM_P = 5, EP_CROSS = 6 };
+constexpr int kMaxCand = 16;
+
+struct RowFusedArgs {
+    const c32* s1;
+    const c32* s2;
+    c32* out;
+    const float* data;
+    const c32* table;
+    long long nrows;
+    double* sums;        // EP_STATS: [2]; EP_PROJECT: [1] cost; EP_LINESEARCH: [ncand + 1]
+    const double* ab;    // device scalars a, b of ptycho.py:342-343 (nullptr: scale 1)
+    float gamma0;
+    int ncand;
+    int xa, xb;          // columns outside [xa, xb) of the inputs are zero (never written)
+    // multi-mode variants (arrays are float32 [positions][ndet][ndet])
+    const float* inten;  // EP_PROJECT: summed intensity of all modes (nullptr: single mode, |g|^2)
+    float* acc1;         // EP_ACCUM_I: intensity;  EP_ACCUM_P: p1
+    float* acc2;         // EP_ACCUM_P: p2
+    float* acc3;         // EP_ACCUM_P: p3
+    int first;           // 1: overwrite the arrays, 0: add to them
+    c32* ip;             // EP_CROSS: image product u1 * conj(u2), [positions][ndet][ndet]
+};
+
+template <int N, int EP>
+__global__ __launch_bounds__(256) void k_rows_fused(const RowFusedArgs a) {
+    using P = Plan<N>;
+    using F = Fft<P, -1>;
+    using L = RowLds<N>;
+    constexpr int E = P::E, T = P::T, B = 256 / T;
+    constexpr int LAST = P::NSTEP - 1;
+    constexpr int NACC = EP == EP_STATS ? 2 : (EP == EP_LINESEARCH ? kMaxCand + 1 : 1);
+    __shared__ c32 lds[P::NSTEP > 1 ? B * L::FS : 1];
+    __shared__ double red[4 * NACC];
+
+    const int tid = threadIdx.x;
+    const int f = tid / T, j0 = tid % T;
+    F fft;
+    fft.init(j0, a.table);
+    const c32 zero = c32{0.0f, 0.0f};
+    float acc[NACC];
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) acc[i] = 0.0f;
+
+    // scale factors of ptycho.py:344-351 in float32, as the reference computes them
+    float s = 1.0f, sinv = 1.0f;
+    if (a.ab) {
+        const float af = (float)a.ab[0], bf = (float)a.ab[1];
+        s = af / bf;
+        sinv = bf / af;
+    }
+
+    // forward DFT over x of one row held as step-0 inputs in v; result in natural order
+    auto fwd_row = [&](c32* v, c32* nat) {
+        fft.template compute<0>(v);
+        if (P::NSTEP > 1) {
+            fft.template store<0>(v, j0, [&](int i, c32 val) { lds[L::at(f, i)] = val; });
+            __syncthreads();
+            fft.template load<1>(v, j0, [&](int i) { return lds[L::at(f, i)]; });
+            if (P::NSTEP > 2) {
+                __syncthreads();
+                fft.template compute<1>(v);
+                fft.template store<1>(v, j0, [&](int i, c32 val) { lds[L::at(f, i)] = val; });
+                __syncthreads();
+                fft.template load<2>(v, j0, [&](int i) { return lds[L::at(f, i)]; });
+            }
+            fft.template compute<LAST>(v);
+            __syncthreads();   // lds free for the next transform
+        }
+        F::to_natural(v, nat);
+    };
+
+    const long long nb = (a.nrows + B - 1) / B;
+    for (long long batch = blockIdx.x; batch < nb; batch += gridDim.x) {
+        const long long r = batch * B + f;
+        const bool ok = r < a.nrows;
+        const size_t rowoff = (size_t)r * N;
+        c32 v[E], g1[E];
+        fft.template load<0>(v, j0, [&](int i) { return (ok && i >= a.xa && i < a.xb) ? __builtin_nontemporal_load(a.s1 + rowoff + i) : zero; });
+        fwd_row(v, g1);
+        float d[E];
+        auto load_data = [&]() {
+#pragma unroll
+            for (int m = 0; m < E; ++m) d[m] = ok ? __builtin_nontemporal_load(a.data + rowoff + j0 + m * T) : 0.0f;
+        };
+        if (EP == EP_STATS || EP == EP_PROJECT) load_data();
+        if (EP == EP_CROSS) {
+            // position correction (ptycho.py:398-403,198-204): u1 = G psi, u2 = G(psi + gamma dpsi)
+            // = u1 + gamma G dpsi (ones probe); image product u1 conj(u2) is kept for the zoomed
+            // DFT and its inverse row DFT goes back into the slot (column pass + arg-max follow).
+            c32 g2[E], rr[E];
+            fft.template load<0>(v, j0, [&](int i) { return (ok && i >= a.xa && i < a.xb) ? __builtin_nontemporal_load(a.s2 + rowoff + i) : zero; });
+            fwd_row(v, g2);
+#pragma unroll
+            for (int m = 0; m < E; ++m) {
+                const c32 u2 = g1[m] + g2[m] * a.gamma0;
+                rr[m] = cmulc(g1[m], u2);
+                if (ok) __builtin_nontemporal_store(rr[m], a.ip + rowoff + j0 + m * T);
+            }
+            F::from_natural(rr, v);
+            fft.template compute_rev<0>(v);
+            if (P::NSTEP > 1) {
+                fft.template store<0>(v, j0, [&](int i, c32 val) { lds[L::at(f, i)] = val; });
+                __syncthreads();
+                fft.template load<1>(v, j0, [&](int i) { return lds[L::at(f, i)]; });
+                if (P::NSTEP > 2) {
+                    __syncthreads();
+                    fft.template compute_rev<1>(v);
+                    fft.template store<1>(v, j0, [&](int i, c32 val) { lds[L::at(f, i)] = val; });
+                    __syncthreads();
+                    fft.template load<2>(v, j0, [&](int i) { return lds[L::at(f, i)]; });
+                }
+                fft.template compute_rev<LAST>(v);
+            }
+            fft.template store<LAST>(v, j0, [&](int i, c32 val) {
+                if (ok) __builtin_nontemporal_store(val, a.out + rowoff + i);
+            });
+            if (P::NSTEP > 1) __syncthreads();
+            continue;
+        }
+
+        if (EP == EP_STATS) {
+#pragma unroll
+            for (int m = 0; m < E; ++m) {
+                const float I = g1[m].x * g1[m].x + g1[m].y * g1[m].y;
+                acc[0] += sqrtf(I * d[m]);
+                acc[1] += I;
+            }
+        } else if (EP == EP_ACCUM_I) {
+            if (ok) {
+#pragma unroll
+                for (int m = 0; m < E; ++m) {
+                    const float I = g1[m].x * g1[m].x + g1[m].y * g1[m].y;
+                    float* o = a.acc1 + rowoff + j0 + m * T;
+                    *o = a.first ? I : *o + I;
+                }
+            }
+        } else if (EP == EP_ACCUM_P) {
+            c32 g2[E];
+            fft.template load<0>(v, j0, [&](int i) { return (ok && i >= a.xa && i < a.xb) ? __builtin_nontemporal_load(a.s2 + rowoff + i) : zero; });
+            fwd_row(v, g2);
+            if (ok) {
+#pragma unroll
+                for (int m = 0; m < E; ++m) {
+                    const size_t o = rowoff + j0 + m * T;
+                    const c32 t1 = g1[m] * s;
+                    const float p1 = t1.x * t1.x + t1.y * t1.y;
+                    const float p2 = g2[m].x * g2[m].x + g2[m].y * g2[m].y;
+                    const float p3 = 2.0f * (t1.x * g2[m].x + t1.y * g2[m].y);
+                    a.acc1[o] = a.first ? p1 : a.acc1[o] + p1;
+                    a.acc2[o] = a.first ? p2 : a.acc2[o] + p2;
+                    a.acc3[o] = a.first ? p3 : a.acc3[o] + p3;
+                }
+            }
+        } else if (EP == EP_PROJECT) {
+            const float s2 = s * s;
+            c32 rr[E];
+#pragma unroll
+            for (int m = 0; m < E; ++m) {
+                // single mode: S comes from the unscaled probe -> I' = |g|^2 s^2, fpsi = (g s)(1/s');
+                // multi mode: S comes from the rescaled probe and I is the summed intensity array
+                const float I = a.inten ? (ok ? a.inten[rowoff + j0 + m * T] : 0.0f) * s2
+                                        : (g1[m].x * g1[m].x + g1[m].y * g1[m].y) * s2;
+                const c32 fp = a.inten ? g1[m] * sinv : (g1[m] * s) * sinv;
+                const float sd = sqrtf(d[m]), sI = sqrtf(I);
+                rr[m] = fp - (fp * sd) / (sI + 1e-32f);
+                const float df = sI - sd;
+                acc[0] += ok ? df * df : 0.0f;
+            }
+            // inverse DFT over x of the projected row, same twiddle registers (conjugated)
+            F::from_natural(rr, v);
+            fft.template compute_rev<0>(v);
+            if (P::NSTEP > 1) {
+                fft.template store<0>(v, j0, [&](int i, c32 val) { lds[L::at(f, i)] = val; });
+                __syncthreads();
+                fft.template load<1>(v, j0, [&](int i) { return lds[L::at(f, i)]; });
+                if (P::NSTEP > 2) {
+                    __syncthreads();
+                    fft.template compute_rev<1>(v);
+                    fft.template store<1>(v, j0, [&](int i, c32 val) { lds[L::at(f, i)] = val; });
+                    __syncthreads();
+                    fft.template load<2>(v, j0, [&](int i) { return lds[L::at(f, i)]; });
+                }
+                fft.template compute_rev<LAST>(v);
+            }
+            fft.template store<LAST>(v, j0, [&](int i, c32 val) {
+                if (ok) __builtin_nontemporal_store(val, a.out + rowoff + i);
+            });
+            if (P::NSTEP > 1) __syncthreads();
+        } else {   // EP_LINESEARCH
+            c32 g2[E];
+            fft.template load<0>(v, j0, [&](int i) { return (ok && i >= a.xa && i < a.xb) ? __builtin_nontemporal_load(a.s2 + rowoff + i) : zero; });
+            fwd_row(v, g2);
+            load_data();   // after the second transform: keeps 16 registers free during it
+#pragma unroll
+            for (int m = 0; m < E; ++m) {
+                const c32 t1 = g1[m] * s;
+                const float p1 = t1.x * t1.x + t1.y * t1.y;
+                const float p2 = g2[m].x * g2[m].x + g2[m].y * g2[m].y;
+                const float p3 = 2.0f * (t1.x * g2[m].x + t1.y * g2[m].y);
+                const float sd = sqrtf(d[m]);
+                float df = sqrtf(fabsf(p1)) - sd;
+                acc[kMaxCand] += df * df;
+                float gam = a.gamma0;
+#pragma unroll
+                for (int j = 0; j < kMaxCand; ++j) {
+                    if (j < a.ncand) {
+                        const float xx = p1 + (gam * gam) * p2 + gam * p3;
+                        df = sqrtf(fabsf(xx)) - sd;
+                        acc[j] += df * df;
+                    }
+                    gam *= 0.5f;
+                }
+            }
+        }
+    }
+    if (EP == EP_ACCUM_I || EP == EP_ACCUM_P || EP == EP_CROSS) return;
+    // ---- block reduction (float partials -> double), one atomic per value per workgroup
+    const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) {
+        double x = (double)acc[i];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) x += __shfl_down(x, off, 64);
+        if (lane == 0) red[wave * NACC + i] = x;
+    }
+    __syncthreads();
+    if (tid < NACC) {
+        const double x = red[tid] + red[NACC + tid] + red[2 * NACC + tid] + red[3 * NACC + tid];
+        if (EP != EP_LINESEARCH || tid < a.ncand || tid == kMaxCand)
+            atomicAdd(a.sums + (EP == EP_LINESEARCH && tid == kMaxCand ? a.ncand : tid), x);
+    }
+}
+
+// elementwise reductions over stored arrays (multi-mode CG path): no DFT involved
+//   MODE 0: sums += { sum sqrt(I d), sum I }                                   (ptycho.py:342-343)
+//   MODE 1: costs[j] += sum (sqrt|p1 + y_j^2 p2 + y_j p3| - sqrt d)^2, costs[ncand] += f(p1)
+constexpr int kArrCand = 32;   // candidates per pass of the array line search
+
+template <int MODE>
+__global__ __launch_bounds__(256) void k_array_reduce(const float* __restrict__ p1, const float* __restrict__ p2,
+                                                      const float* __restrict__ p3, const float* __restrict__ d,
+                                                      const long long n, const float gamma0, const int ncand,
+                                                      double* __restrict__ sums) {
+    constexpr int NACC = MODE == 0 ? 2 : kArrCand + 1;
+    __shared__ double red[4 * NACC];
+    float acc[NACC];
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) acc[i] = 0.0f;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const float dd = d[i];
+        if (MODE == 0) {
+            const float I = p1[i];
+            acc[0] += sqrtf(I * dd);
+            acc[1] += I;
+        } else {
+            const float a1 = p1[i], a2 = p2[i], a3 = p3[i];
+            const float sd = sqrtf(dd);
+            float df = sqrtf(fabsf(a1)) - sd;
+            acc[kArrCand] += df * df;
+            float gam = gamma0;
+#pragma unroll
+            for (int j = 0; j < kArrCand; ++j) {
+                if (j < ncand) {
+                    df = sqrtf(fabsf(a1 + (gam * gam) * a2 + gam * a3)) - sd;
+                    acc[j] += df * df;
+                }
+                gam *= 0.5f;
+            }
+        }
+    }
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) {
+        double x = (double)acc[i];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) x += __shfl_down(x, off, 64);
+        if (lane == 0) red[wave * NACC + i] = x;
+    }
+    __syncthreads();
+    if (tid < NACC) {
+        const double x = red[tid] + red[NACC + tid] + red[2 * NACC + tid] + red[3 * NACC + tid];
+        if (MODE == 0 || tid < ncand || tid == kArrCand) atomicAdd(sums + (MODE == 1 && tid == kArrCand ? ncand : tid), x);
+    }
+}
