@@ -23,8 +23,10 @@ struct WinCfg {
     static constexpr bool fits = (size_t)((N + 2) * (C + 2) + H * WC) * sizeof(c32) <= 160 * 1024;
 };
 
-template <int N>
+template <int N, bool SPLIT = false>
 __global__ __launch_bounds__(ColCfg<N>::NT) void k_cols_adjwin(const ColArgs a, const int seglen) {
+    // SPLIT (N = 256): the tile already went through the first radix-16 step in k_rows_split;
+    // only the twiddled second step runs here, straight from global memory (no exchange).
     using P = Plan<N>;
     using F = Fft<P, +1>;
     constexpr int E = P::E, T = P::T, C = ColCfg<N>::C, NT = ColCfg<N>::NT;
@@ -108,16 +110,16 @@ __global__ __launch_bounds__(ColCfg<N>::NT) void k_cols_adjwin(const ColArgs a, 
     if (st.have && st.q.valid) {
         const c32* tile_in = tile_of(st, kb);
         if (a.nt & 8)
-            fft.template load<0>(v, j0, [&](int i) { return __builtin_nontemporal_load(tile_in + (size_t)i * N + x); });
+            fft.template load<(SPLIT ? 1 : 0)>(v, j0, [&](int i) { return __builtin_nontemporal_load(tile_in + (size_t)i * N + x); });
         else
-            fft.template load<0>(v, j0, [&](int i) { return tile_in[(size_t)i * N + x]; });
+            fft.template load<(SPLIT ? 1 : 0)>(v, j0, [&](int i) { return tile_in[(size_t)i * N + x]; });
     }
     for (int k = kb; k < ke; ++k) {
         St nx = decode(k + 1);
         if (!st.q.valid) {   // skipped position: nothing to add; fetch the next tile
             if (nx.have && nx.q.valid) {
                 const c32* tile_in = tile_of(nx, k + 1);
-                fft.template load<0>(v, j0, [&](int i) { return tile_in[(size_t)i * N + x]; });
+                fft.template load<(SPLIT ? 1 : 0)>(v, j0, [&](int i) { return tile_in[(size_t)i * N + x]; });
             }
             st = nx;
             continue;
@@ -135,6 +137,9 @@ __global__ __launch_bounds__(ColCfg<N>::NT) void k_cols_adjwin(const ColArgs a, 
             cur_t = st.t;
         }
         // ---- inverse DFT over y of this strip (tile already in v) ----------------------
+        if (SPLIT) {
+            fft.template compute<LAST>(v);   // twiddle + radix 16: the step k_rows_split left
+        } else {
         fft.template compute<0>(v);
         if (P::NSTEP > 1) {
             fft.template store<0>(v, j0, [&](int i, c32 val) { lds[at(i)] = val; });
@@ -148,6 +153,7 @@ __global__ __launch_bounds__(ColCfg<N>::NT) void k_cols_adjwin(const ColArgs a, 
                 fft.template load<2>(v, j0, [&](int i) { return lds[at(i)]; });
             }
             fft.template compute<LAST>(v);
+        }
         }
         // ---- T[y][c] = conj(c * prb) * near, written over the slots this thread just read ----
         {
@@ -163,9 +169,9 @@ __global__ __launch_bounds__(ColCfg<N>::NT) void k_cols_adjwin(const ColArgs a, 
         if (nx.have && nx.q.valid) {
             const c32* tile_in = tile_of(nx, k + 1);
             if (a.nt & 8)
-                fft.template load<0>(v, j0, [&](int i) { return __builtin_nontemporal_load(tile_in + (size_t)i * N + x); });
+                fft.template load<(SPLIT ? 1 : 0)>(v, j0, [&](int i) { return __builtin_nontemporal_load(tile_in + (size_t)i * N + x); });
             else
-                fft.template load<0>(v, j0, [&](int i) { return tile_in[(size_t)i * N + x]; });
+                fft.template load<(SPLIT ? 1 : 0)>(v, j0, [&](int i) { return tile_in[(size_t)i * N + x]; });
         }
         // ---- window bookkeeping (all quantities are workgroup-uniform) -------------------
         const int Xa = q.sx + x0 - ge.pad;   // object column of strip column cc = 0
@@ -227,8 +233,10 @@ __global__ __launch_bounds__(ColCfg<N>::NT) void k_cols_adjwin(const ColArgs a, 
 //   M_FWD     : v = (c*prb) * bilerp(window)  -> DFT over y -> strip of g
 //   M_ADJ_PRB : IDFT over y of the scratch strip; acc += near * conj(bilerp(window))
 // ---------------------------------------------------------------------------
-template <int N, int MODE>
+template <int N, int MODE, bool SPLIT = false>
 __global__ __launch_bounds__(ColCfg<N>::NT) void k_cols_gatherwin(const ColArgs a, const int seglen) {
+    // SPLIT (N = 256): only one radix-16 step of the DFT over y runs here (thread local, no
+    // exchange buffer -> 44 KiB of LDS, three workgroups per CU); k_rows_split does the other.
     using P = Plan<N>;
     constexpr int DIR = (MODE == M_FWD) ? -1 : +1;
     using F = Fft<P, DIR>;
@@ -236,7 +244,7 @@ __global__ __launch_bounds__(ColCfg<N>::NT) void k_cols_gatherwin(const ColArgs 
     constexpr int LAST = P::NSTEP - 1;
     constexpr int WC = WinCfg<N>::WC, H = WinCfg<N>::H;
     constexpr int R0 = P::radix(0), RL = P::radix(LAST), NsL = P::ns(LAST);
-    __shared__ c32 lds[N * C];
+    __shared__ c32 lds[SPLIT ? 1 : N * C];
     __shared__ c32 win[H * WC];
 
     const int tid = threadIdx.x;
@@ -360,7 +368,7 @@ __global__ __launch_bounds__(ColCfg<N>::NT) void k_cols_gatherwin(const ColArgs 
         };
         auto load_tile = [&](c32* v, const St& st, int k) {
             const c32* tile_in = a.src + (size_t)(a.natural_tiles ? st.p : (k - a.k_begin)) * N * N;
-            fft.template load<0>(v, j0, [&](int i) { return tile_in[(size_t)i * N + x]; });
+            fft.template load<(SPLIT ? 1 : 0)>(v, j0, [&](int i) { return tile_in[(size_t)i * N + x]; });
         };
         __syncthreads();   // run metadata visible
         St st = decode_only(kb);
@@ -379,15 +387,17 @@ __global__ __launch_bounds__(ColCfg<N>::NT) void k_cols_gatherwin(const ColArgs 
                 for (int m = 0; m < E; ++m) pr[m] = zero;
                 cur_t = st.t;
             }
-            fft.template compute<0>(v);
-            if (P::NSTEP > 1) {
+            if (!SPLIT) fft.template compute<0>(v);
+            if (!SPLIT && P::NSTEP > 1) {
                 fft.template store<0>(v, j0, [&](int i, c32 val) { lds[i * C + c] = val; });
                 __syncthreads();   // also: the accumulation of k-1 is over, the window may move
             } else {
                 __syncthreads();
             }
             const St cur = prepare_issue(k, ke);   // same decode as st, plus the window update
-            if (P::NSTEP > 1) {
+            if (SPLIT) {
+                fft.template compute<LAST>(v);
+            } else if (P::NSTEP > 1) {
                 fft.template load<1>(v, j0, [&](int i) { return lds[i * C + c]; });
                 if (P::NSTEP > 2) {
                     __syncthreads();
@@ -493,6 +503,17 @@ __global__ __launch_bounds__(ColCfg<N>::NT) void k_cols_gatherwin(const ColArgs 
         }
         fft.template compute<0>(v);
         St nx;
+        if (SPLIT && MODE == M_FWD) {
+            // the radix-16 outputs go straight to rows 16 j0 + k1 of the strip (Stockham step 0)
+            c32* tile_out = a.dst + (size_t)st.p * N * N;
+            fft.template store<0>(v, j0, [&](int i, c32 val) { tile_out[(size_t)i * N + x] = val; });
+            __syncthreads();   // every bilinear read of position k is done
+            nx = prepare_issue(k + 1, ke);
+            prepare_commit();
+            __syncthreads();
+            st = nx;
+            continue;
+        }
         if (P::NSTEP > 1) {
             fft.template store<0>(v, j0, [&](int i, c32 val) { lds[i * C + c] = val; });
             __syncthreads();

@@ -60,6 +60,92 @@ __global__ __launch_bounds__(256) void k_rows(const RowArgs a) {
 }
 
 // ---------------------------------------------------------------------------
+// Split variant for N = 256 (= 16 x 16): the column kernels do only ONE radix-16 step of
+// the DFT over y (thread local, no exchange, no barrier); the other radix-16 step runs
+// here, across the 16 rows {jp + 16 t} a workgroup owns, where the kernel is HBM bound
+// and has ALU slack.  Stockham algebra: step 0 maps x[j + 16 t] -> y0[16 j + k1]; step 1
+// maps y0[j' + 16 t] * W^{j' t} -> X[j' + 16 t'].
+//   DIR < 0 (forward): rows j' + 16 t of the intermediate -> twiddle -> radix 16 over t
+//                      -> transpose through LDS -> DFT over x -> final rows j' + 16 t'.
+//   DIR > 0 (adjoint): rows j' + 16 f of g -> IDFT over x -> transpose -> radix 16 over
+//                      the 16 rows (step 0, no twiddle) -> intermediate rows 16 j' + k1.
+// ---------------------------------------------------------------------------
+template <int N, int DIR>
+__global__ __launch_bounds__(256) void k_rows_split(const RowArgs a) {
+    static_assert(N == 256, "split row pass is written for the 16 x 16 plan");
+    using P = Plan<N>;
+    using F = Fft<P, DIR>;
+    using L = RowLds<N>;
+    constexpr int E = P::E, T = P::T, B = 256 / T;   // 16, 16, 16
+    constexpr int LAST = P::NSTEP - 1;
+    __shared__ c32 lds[B * L::FS];
+
+    const int tid = threadIdx.x;
+    const int f = tid / T, j0 = tid % T;
+    F fft;
+    fft.init(j0, a.table);
+    const c32 zero = c32{0.0f, 0.0f};
+    const long long nitems = (a.nrows / N) * 16;
+    for (long long item = blockIdx.x; item < nitems; item += gridDim.x) {
+        const long long tile = item / 16;
+        const int jp = (int)(item % 16);
+        const long long stile = a.tile_index ? (long long)a.tile_index[tile] : tile;
+        const c32* sbase = a.src + (size_t)stile * N * N;
+        c32* dbase = a.dst + (size_t)((a.dst_indexed && a.tile_index) ? stile : tile) * N * N;
+        c32 v[E];
+        if (DIR < 0) {
+            // ---- second radix-16 step of the DFT over y, thread = column x ------------------
+            const int x = tid;
+            const bool colok = x >= a.xa && x < a.xb;
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const c32 val = __builtin_nontemporal_load(sbase + (size_t)(jp + 16 * t) * N + x);
+                v[t] = colok ? val : zero;
+            }
+#pragma unroll
+            for (int t = 1; t < 16; ++t) v[t] = cmul(v[t], a.table[(jp * t) & (N - 1)]);   // uniform index
+            fft_reg<16, -1>(v);
+#pragma unroll
+            for (int t = 0; t < 16; ++t) lds[L::at(t, x)] = v[brev(t, 4)];
+            __syncthreads();
+            // ---- DFT over x of row f (final row jp + 16 f) ---------------------------------
+            fft.template load<0>(v, j0, [&](int i) { return lds[L::at(f, i)]; });
+            fft.template compute<0>(v);
+            fft.template store<0>(v, j0, [&](int i, c32 val) { lds[L::at(f, i)] = val; });
+            __syncthreads();
+            fft.template load<1>(v, j0, [&](int i) { return lds[L::at(f, i)]; });
+            fft.template compute<LAST>(v);
+            c32* drow = dbase + (size_t)(jp + 16 * f) * N;
+            fft.template store<LAST>(v, j0, [&](int i, c32 val) { __builtin_nontemporal_store(val, drow + i); });
+            __syncthreads();
+        } else {
+            // ---- IDFT over x of row jp + 16 f of g ------------------------------------------
+            const c32* srow = sbase + (size_t)(jp + 16 * f) * N;
+            fft.template load<0>(v, j0, [&](int i) { return __builtin_nontemporal_load(srow + i); });
+            fft.template compute<0>(v);
+            fft.template store<0>(v, j0, [&](int i, c32 val) { lds[L::at(f, i)] = val; });
+            __syncthreads();
+            fft.template load<1>(v, j0, [&](int i) { return lds[L::at(f, i)]; });
+            fft.template compute<LAST>(v);
+            __syncthreads();   // every exchange read is done before the rows are rewritten
+            fft.template store<LAST>(v, j0, [&](int i, c32 val) { lds[L::at(f, i)] = val; });
+            __syncthreads();
+            // ---- first radix-16 step of the IDFT over y, thread = column x -------------------
+            const int x = tid;
+#pragma unroll
+            for (int t = 0; t < 16; ++t) v[t] = lds[L::at(t, x)];
+            fft_reg<16, +1>(v);
+            if (x >= a.wa && x < a.wb) {
+#pragma unroll
+                for (int k1 = 0; k1 < 16; ++k1)
+                    __builtin_nontemporal_store(v[brev(k1, 4)], dbase + (size_t)(16 * jp + k1) * N + x);
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // Row pass fused with the elementwise stages of the CG loop
 // (src/libtike/cufft/ptycho.py:325-393 launches each of them as separate CuPy
 // kernels over farplane-sized temporaries).  Input rows are column-pass

@@ -80,6 +80,7 @@ struct ptycho_handle_s {
     c32* work[2] = {nullptr, nullptr};   // CG work buffers (column-pass intermediates), all positions
     int use_window = 1;       // 0: direct-atomics object adjoint (k_cols<ADJ_OBJ>)
     int use_team = 0;         // 1: forward operator as one persistent XCD-team launch (experimental)
+    int use_split = 1;        // ndet = 256: one radix-16 step of the DFT over y runs in the row pass
     int use_pipeline = 0;     // 1: column and row passes of neighbouring chunks overlap on two streams (experimental)
     int profile_serial = 0;   // 1: no pipelining (set while the in-library profiler times kernels one by one)
     hipStream_t aux = nullptr;               // second stream of the pipeline
@@ -159,7 +160,7 @@ int launch_cols(ptycho_handle h, ColArgs a, hipStream_t st) {
     return PTYCHO_OK;
 }
 
-template <int N>
+template <int N, bool SPLIT = false>
 int launch_adjwin(ptycho_handle h, ColArgs a, hipStream_t st, int wg_target = 0) {
     using CC = ColCfg<N>;
     const int np = a.k_end - a.k_begin;
@@ -176,18 +177,18 @@ int launch_adjwin(ptycho_handle h, ColArgs a, hipStream_t st, int wg_target = 0)
     a.nt = nt_mode_a;
     {
         ProfSpan ps(h, K_COLS_ADJ_OBJ, st);
-        hipLaunchKernelGGL((k_cols_adjwin<N>), dim3((unsigned)(a.nstrips * nseg)), dim3(CC::NT), 0, st, a, seglen);
+        hipLaunchKernelGGL((k_cols_adjwin<N, SPLIT>), dim3((unsigned)(a.nstrips * nseg)), dim3(CC::NT), 0, st, a, seglen);
     }
     HIP_TRY(hipGetLastError());
     return PTYCHO_OK;
 }
 
-template <int N, int MODE>
+template <int N, int MODE, bool SPLIT = false>
 int launch_gatherwin(ptycho_handle h, ColArgs a, hipStream_t st, int wg_target = 0) {
     using CC = ColCfg<N>;
     const int np = a.k_end - a.k_begin;
     if (np <= 0 || a.nstrips <= 0) return PTYCHO_OK;
-    if (wg_target <= 0) wg_target = h->n_cu * 4;
+    if (wg_target <= 0) wg_target = h->n_cu * (SPLIT ? 6 : 4);   // split kernels fit three per CU
     int nseg = (wg_target + a.nstrips - 1) / a.nstrips;
     if (nseg < 1) nseg = 1;
     int seglen = (np + nseg - 1) / nseg;
@@ -206,7 +207,7 @@ int launch_gatherwin(ptycho_handle h, ColArgs a, hipStream_t st, int wg_target =
     a.nt = nt_mode_g;
     {
         ProfSpan ps(h, MODE == M_FWD ? K_COLS_FWD : K_COLS_ADJ_PRB, st);
-        hipLaunchKernelGGL((k_cols_gatherwin<N, MODE>), dim3((unsigned)(a.nstrips * nseg)), dim3(CC::NT), 0, st, a, seglen);
+        hipLaunchKernelGGL((k_cols_gatherwin<N, MODE, SPLIT>), dim3((unsigned)(a.nstrips * nseg)), dim3(CC::NT), 0, st, a, seglen);
     }
     HIP_TRY(hipGetLastError());
     return PTYCHO_OK;
@@ -225,6 +226,19 @@ int launch_rows(ptycho_handle h, RowArgs a, hipStream_t st) {
     {
         ProfSpan ps(h, DIR < 0 ? K_ROWS_FWD : K_ROWS_INV, st);
         hipLaunchKernelGGL((k_rows<N, DIR>), dim3((unsigned)grid), dim3(256), 0, st, a);
+    }
+    HIP_TRY(hipGetLastError());
+    return PTYCHO_OK;
+}
+
+template <int N, int DIR>
+int launch_rows_split(ptycho_handle h, RowArgs a, hipStream_t st) {
+    if (a.nrows <= 0) return PTYCHO_OK;
+    const long long nitems = (a.nrows / N) * 16;
+    long long grid = nitems < (long long)h->n_cu * 8 ? nitems : (long long)h->n_cu * 8;
+    {
+        ProfSpan ps(h, DIR < 0 ? K_ROWS_FWD : K_ROWS_INV, st);
+        hipLaunchKernelGGL((k_rows_split<N, DIR>), dim3((unsigned)grid), dim3(256), 0, st, a);
     }
     HIP_TRY(hipGetLastError());
     return PTYCHO_OK;
@@ -370,6 +384,17 @@ int do_fwd(ptycho_handle h, c32* g, const c32* f, const float* scan, const c32* 
     ColArgs ca{};
     ca.src = f; ca.dst = g; ca.aux = prb; ca.scan = scan; ca.table = h->table; ca.ge = ge;
     ca.k_begin = 0; ca.k_end = (int)total; ca.strip0 = strip0; ca.nstrips = nstrips;
+    RowArgs ra{};
+    ra.src = g; ra.dst = g; ra.table = h->table; ra.tile_index = nullptr;
+    ra.nrows = total * N; ra.xa = strip0 * C; ra.xb = (strip0 + nstrips) * C; ra.wa = 0; ra.wb = N;
+    if constexpr (N == 256) {
+        if (window && h->use_split) {
+            ca.order = h->order;
+            rc = launch_gatherwin<N, M_FWD, true>(h, ca, st);
+            if (rc) return rc;
+            return launch_rows_split<N, -1>(h, ra, st);
+        }
+    }
     if (window) {
         ca.order = h->order;
         if constexpr (WinCfg<N>::fits) rc = launch_gatherwin<N, M_FWD>(h, ca, st);
@@ -378,9 +403,6 @@ int do_fwd(ptycho_handle h, c32* g, const c32* f, const float* scan, const c32* 
         rc = launch_cols<N, -1, M_FWD>(h, ca, st);
     }
     if (rc) return rc;
-    RowArgs ra{};
-    ra.src = g; ra.dst = g; ra.table = h->table; ra.tile_index = nullptr;
-    ra.nrows = total * N; ra.xa = strip0 * C; ra.xb = (strip0 + nstrips) * C; ra.wa = 0; ra.wb = N;
     return launch_rows<N, -1>(h, ra, st);
 }
 
@@ -439,11 +461,29 @@ int do_adj(ptycho_handle h, c32* f, const c32* g, const float* scan, c32* prb, i
         RowArgs ra{};
         ra.src = g; ra.dst = h->scratch; ra.table = h->table; ra.tile_index = h->order + k0;
         ra.nrows = (k1 - k0) * N; ra.xa = 0; ra.xb = N; ra.wa = strip0 * C; ra.wb = (strip0 + nstrips) * C;
-        rc = launch_rows<N, +1>(h, ra, st);
+        bool split = false;
+        if constexpr (N == 256) split = h->use_split && h->use_window;
+        if constexpr (N == 256) {
+            if (split) rc = launch_rows_split<N, +1>(h, ra, st);
+        }
+        if (!split) rc = launch_rows<N, +1>(h, ra, st);
         if (rc) return rc;
         ColArgs ca{};
         ca.src = h->scratch; ca.scan = scan; ca.table = h->table; ca.ge = ge;
         ca.order = h->order; ca.k_begin = (int)k0; ca.k_end = (int)k1; ca.strip0 = strip0; ca.nstrips = nstrips;
+        if constexpr (N == 256) {
+            if (split) {
+                if (flg == 0) {
+                    ca.dst = f; ca.aux = prb;
+                    rc = launch_adjwin<N, true>(h, ca, st);
+                } else {
+                    ca.dst = prb; ca.aux = f;
+                    rc = launch_gatherwin<N, M_ADJ_PRB, true>(h, ca, st);
+                }
+                if (rc) return rc;
+                continue;
+            }
+        }
         if (flg == 0) {
             ca.dst = f; ca.aux = prb;
             if (window) {
@@ -674,6 +714,8 @@ int ptycho_create(ptycho_handle* out, size_t ptheta, size_t nz, size_t n, size_t
     }
     const char* env = std::getenv("PTYCHO_HIP_WINDOW");
     if (env) h->use_window = std::atoi(env) != 0;
+    env = std::getenv("PTYCHO_HIP_SPLIT");
+    if (env) h->use_split = std::atoi(env) != 0;
     env = std::getenv("PTYCHO_HIP_PIPELINE");
     if (env) h->use_pipeline = std::atoi(env) != 0;
     env = std::getenv("PTYCHO_HIP_TEAM");
@@ -744,6 +786,10 @@ int ptycho_set_option(ptycho_handle h, const char* name, long long value) {
     if (std::strcmp(name, "trust_order") == 0) {
         h->trust_order = value != 0;
         if (!h->trust_order) h->order_scan = nullptr;
+        return PTYCHO_OK;
+    }
+    if (std::strcmp(name, "split") == 0) {
+        h->use_split = value != 0;
         return PTYCHO_OK;
     }
     if (std::strcmp(name, "pipeline") == 0) {
