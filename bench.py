@@ -183,8 +183,7 @@ def main():
     traffic, traffic_src = None, None
     try:
         tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
-        names = {"k_cols<FWD>": "k_cols_gatherwin<256, 1>", "k_rows<fwd>": "k_rows<256, -1>",
-                 "k_rows<inv>": "k_rows<256, 1>", "k_cols<ADJ_OBJ>": "k_cols_adjwin<256>"}
+        names = tj["roles"]     # bench kernel role -> rocprof kernel name of the profiled build
         if ndet == 256 and nprb == 256 and nscan == 4096 and all(names.get(k, "") in tj["kernels"] for k in kern):
             traffic = sum(tj["kernels"][names[k]].get("fetch_bytes_per_launch", 0.0)
                           + tj["kernels"][names[k]].get("write_bytes_per_launch", 0.0) for k in kern)

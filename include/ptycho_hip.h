@@ -132,6 +132,7 @@ int ptycho_cg_argmax(ptycho_handle h, int slot, void* best, void* stream);
  * "trust_order" (1 = the caller vouches that the scan buffer passed to the next calls is the
  * same pointer with unchanged contents as in the previous call, so the position sort is
  * reused; set 0 after modifying scan; default 0);
+ * "split" (ndet = 256: 1 = one radix-16 step of the DFT over y runs in the row pass [default]);
  * "pipeline" (1 = chunked two-stream overlap of column and row passes; experimental, default 0);
  * "team" (1 = forward operator as one persistent launch of per-XCD teams that keep the
  * column->row intermediate in L2; experimental, default 0).  ptycho_get(h, 102) returns

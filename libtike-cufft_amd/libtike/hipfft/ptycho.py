@@ -134,6 +134,10 @@ class PtychoHIP:
         """Object adjoint: LDS overlap-add window (default) or direct atomics."""
         nat.check(nat.set_option(self._h, b"window", int(bool(on))))
 
+    def set_split(self, on=True):
+        """ndet = 256: split the DFT over y between the column and the row pass (default on)."""
+        nat.check(nat.set_option(self._h, b"split", int(bool(on))))
+
     def set_pipeline(self, on=True):
         """Chunked two-stream overlap of column and row passes (experimental, off by default)."""
         nat.check(nat.set_option(self._h, b"pipeline", int(bool(on))))

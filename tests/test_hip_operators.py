@@ -193,6 +193,11 @@ def test_experimental_paths_give_the_same_results(pt):
         slv.set_pipeline(True)
         got = [host(slv.fwd(psi, scan, prb)), host(slv.adj(yd, scan, prb)), host(slv.adj_probe(yd, scan, psi))]
         slv.set_pipeline(False)
+        slv.set_split(False)               # unsplit column / row kernels
+        uns = [host(slv.fwd(psi, scan, prb)), host(slv.adj(yd, scan, prb)), host(slv.adj_probe(yd, scan, psi))]
+        slv.set_split(True)
+        for a, b in zip(uns, ref):
+            assert np.abs(a - b).max() <= 1e-5 * np.abs(b).max()
         slv.set_team(True)
         team = host(slv.fwd(psi, scan, prb))
         assert not slv.team_aborted()
