@@ -44,7 +44,7 @@ def parse():
     ap.add_argument("--nprb", type=int, default=256)
     ap.add_argument("--raster", type=int, default=64, help="raster is RxR positions per GPU")
     ap.add_argument("--step-px", type=int, default=8)
-    ap.add_argument("--cg-iters", type=int, default=6)
+    ap.add_argument("--cg-iters", type=int, default=50)   # BASELINE.json configs[1]: 50 CG iterations
     ap.add_argument("--chunk", type=int, default=0)
     ap.add_argument("--cpu-sample", type=int, default=192)
     ap.add_argument("--no-cpu", action="store_true")
@@ -223,7 +223,9 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         cg = {"cg_iterations_per_s": args.cg_iters / dt, "cg_iters_timed": args.cg_iters,
-              "cg_config": "gaussian, 1 mode, no probe recovery, position correction on (reference loop)"}
+              "cg_ms_per_iteration": dt / args.cg_iters * 1e3,
+              "cg_config": "gaussian, 1 mode, no probe recovery, position correction on (reference loop), "
+                           "initial object = 1, timed from iteration 0"}
         del data
 
     out = {

@@ -127,6 +127,18 @@ int ptycho_cg_cross(ptycho_handle h, int slot1, int slot2, double gamma, void* i
                     void* stream);
 int ptycho_cg_argmax(ptycho_handle h, int slot, void* best, void* stream);
 
+/* Sub-pixel stage of the registration (ptycho.py:163-188, 217-235): zoomed matrix DFT of the
+ * image product on an ups x ups window around each whole-pixel peak with a fused arg-max,
+ *   cross[i,j2,j1] = sum_p sum_k py[i,p] K[j2,p] ip[i,p,k] px[i,k] K[j1,k],  best[i] = argmax |cross[i]|
+ * (flat index j2 * ups + j1, first maximum).  px, py: complex128 [ptheta*nscan][ndet], the
+ * per-pattern phases exp(+i th (c0 - offset)); the centred window kernel
+ * K[j,k] = exp(+i th_k (j - c0)) is passed as real low-rank factors
+ *   K = sum_{r<nc} lz[j,r] vt[k,r] + i sum_{r>=nc} lz[j,r] vt[k,r],
+ * vt: float64 [ndet][16], lz: float64 [ups][16] (cos terms first, then sin terms).
+ * Needs ndet % 16 == 0, ndet <= 1024, ups <= max(256, ndet).  best: int32 [ptheta*nscan]. */
+int ptycho_cg_zoom(ptycho_handle h, const void* image_product, const void* px, const void* py,
+                   const void* vt, const void* lz, int nc, int ups, void* best, void* stream);
+
 /* Tuning knobs: "chunk" (positions per launch pair, 0 = default);
  * "window" (1 = LDS overlap-add object adjoint [default], 0 = direct atomics);
  * "trust_order" (1 = the caller vouches that the scan buffer passed to the next calls is the
@@ -145,7 +157,7 @@ int ptycho_set_option(ptycho_handle h, const char* name, long long value);
  * (index 0 k_cols<FWD>, 1 k_rows<fwd>, 2 k_rows<inv>, 3 k_cols<ADJ_OBJ>,
  * 4 k_cols<ADJ_PRB>, 5 k_cols<PLAIN>, 6 position sort, 7-9 fused CG row passes,
  * 10 k_fwd_team, 11 accumulate row passes, 12 array reductions, 13 cross row pass,
- * 14 arg-max column pass; n >= 15)
+ * 14 arg-max column pass, 15 zoomed DFT + arg-max; n >= 16)
  * and clears the record.
  * No counterpart in the reference (it has no timing code). */
 int ptycho_profile(ptycho_handle h, int enable);

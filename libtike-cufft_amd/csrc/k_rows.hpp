@@ -158,6 +158,11 @@ __global__ __launch_bounds__(256) void k_rows_split(const RowArgs a) {
 //                 sum (sqrt|p1 + y^2 p2 + y p3| - sqrt d)^2 for y = gamma0 * 2^-j, j < ncand,
 //                 plus f(p1) -- every trial of line_search_sqr in one pass (ptycho.py:253-281)
 // ---------------------------------------------------------------------------
+// v_sqrt_f32 / v_rcp_f32 (1 ulp).  The correctly rounded sqrtf()/division expand to ~15
+// instructions each; the line search evaluates 17 square roots per farplane element.
+__device__ __forceinline__ float fsqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+__device__ __forceinline__ float frcp(float x) { return __builtin_amdgcn_rcpf(x); }
+
 enum RowEp { EP_STATS = 1, EP_PROJECT = 2, EP_LINESEARCH = 3, EP_ACCUM_I = 4, EP_ACCUM_P = 5, EP_CROSS = 6 };
 constexpr int kMaxCand = 16;
 
@@ -283,7 +288,7 @@ __global__ __launch_bounds__(256) void k_rows_fused(const RowFusedArgs a) {
 #pragma unroll
             for (int m = 0; m < E; ++m) {
                 const float I = g1[m].x * g1[m].x + g1[m].y * g1[m].y;
-                acc[0] += sqrtf(I * d[m]);
+                acc[0] += fsqrt(I * d[m]);
                 acc[1] += I;
             }
         } else if (EP == EP_ACCUM_I) {
@@ -322,8 +327,8 @@ __global__ __launch_bounds__(256) void k_rows_fused(const RowFusedArgs a) {
                 const float I = a.inten ? (ok ? a.inten[rowoff + j0 + m * T] : 0.0f) * s2
                                         : (g1[m].x * g1[m].x + g1[m].y * g1[m].y) * s2;
                 const c32 fp = a.inten ? g1[m] * sinv : (g1[m] * s) * sinv;
-                const float sd = sqrtf(d[m]), sI = sqrtf(I);
-                rr[m] = fp - (fp * sd) / (sI + 1e-32f);
+                const float sd = fsqrt(d[m]), sI = fsqrt(I);
+                rr[m] = fp - (fp * sd) * frcp(sI + 1e-32f);
                 const float df = sI - sd;
                 acc[0] += ok ? df * df : 0.0f;
             }
@@ -358,15 +363,15 @@ __global__ __launch_bounds__(256) void k_rows_fused(const RowFusedArgs a) {
                 const float p1 = t1.x * t1.x + t1.y * t1.y;
                 const float p2 = g2[m].x * g2[m].x + g2[m].y * g2[m].y;
                 const float p3 = 2.0f * (t1.x * g2[m].x + t1.y * g2[m].y);
-                const float sd = sqrtf(d[m]);
-                float df = sqrtf(fabsf(p1)) - sd;
+                const float sd = fsqrt(d[m]);
+                float df = fsqrt(fabsf(p1)) - sd;
                 acc[kMaxCand] += df * df;
                 float gam = a.gamma0;
 #pragma unroll
                 for (int j = 0; j < kMaxCand; ++j) {
                     if (j < a.ncand) {
                         const float xx = p1 + (gam * gam) * p2 + gam * p3;
-                        df = sqrtf(fabsf(xx)) - sd;
+                        df = fsqrt(fabsf(xx)) - sd;
                         acc[j] += df * df;
                     }
                     gam *= 0.5f;
@@ -411,18 +416,18 @@ __global__ __launch_bounds__(256) void k_array_reduce(const float* __restrict__ 
         const float dd = d[i];
         if (MODE == 0) {
             const float I = p1[i];
-            acc[0] += sqrtf(I * dd);
+            acc[0] += fsqrt(I * dd);
             acc[1] += I;
         } else {
             const float a1 = p1[i], a2 = p2[i], a3 = p3[i];
-            const float sd = sqrtf(dd);
-            float df = sqrtf(fabsf(a1)) - sd;
+            const float sd = fsqrt(dd);
+            float df = fsqrt(fabsf(a1)) - sd;
             acc[kArrCand] += df * df;
             float gam = gamma0;
 #pragma unroll
             for (int j = 0; j < kArrCand; ++j) {
                 if (j < ncand) {
-                    df = sqrtf(fabsf(a1 + (gam * gam) * a2 + gam * a3)) - sd;
+                    df = fsqrt(fabsf(a1 + (gam * gam) * a2 + gam * a3)) - sd;
                     acc[j] += df * df;
                 }
                 gam *= 0.5f;

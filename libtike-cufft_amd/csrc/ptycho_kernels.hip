@@ -42,6 +42,7 @@ namespace {
 #include "k_rows.hpp"
 #include "k_cols_window.hpp"
 #include "k_team.hpp"
+#include "k_zoom.hpp"
 
 // ---------------------------------------------------------------------------
 // host side
@@ -49,7 +50,7 @@ namespace {
 thread_local std::string g_err;
 
 // kernel ids for the in-library profiler (ptycho_profile_read)
-enum { K_COLS_FWD = 0, K_ROWS_FWD = 1, K_ROWS_INV = 2, K_COLS_ADJ_OBJ = 3, K_COLS_ADJ_PRB = 4, K_COLS_PLAIN = 5, K_SORT = 6, K_ROWS_STATS = 7, K_ROWS_PROJECT = 8, K_ROWS_LINESEARCH = 9, K_FWD_TEAM = 10, K_ROWS_ACCUM = 11, K_ARRAY_REDUCE = 12, K_ROWS_CROSS = 13, K_COLS_ARGMAX = 14, K_COUNT = 15 };
+enum { K_COLS_FWD = 0, K_ROWS_FWD = 1, K_ROWS_INV = 2, K_COLS_ADJ_OBJ = 3, K_COLS_ADJ_PRB = 4, K_COLS_PLAIN = 5, K_SORT = 6, K_ROWS_STATS = 7, K_ROWS_PROJECT = 8, K_ROWS_LINESEARCH = 9, K_FWD_TEAM = 10, K_ROWS_ACCUM = 11, K_ARRAY_REDUCE = 12, K_ROWS_CROSS = 13, K_COLS_ARGMAX = 14, K_ZOOM = 15, K_COUNT = 16 };
 
 int fail(int code, const std::string& msg) {
     g_err = msg;
@@ -817,7 +818,7 @@ int ptycho_profile(ptycho_handle h, int enable) {
 int ptycho_profile_read(ptycho_handle h, double* ms, long long* launches, int n) {
     int rc = check_handle(h);
     if (rc) return rc;
-    if (!ms || !launches || n < K_COUNT) return fail(PTYCHO_ERR_ARG, "need arrays of at least 15 entries");
+    if (!ms || !launches || n < K_COUNT) return fail(PTYCHO_ERR_ARG, "need arrays of at least 16 entries");
     for (int i = 0; i < n; ++i) { ms[i] = 0.0; launches[i] = 0; }
     for (auto& sp : h->spans) {
         HIP_TRY(hipEventSynchronize(sp.b));
@@ -1034,4 +1035,42 @@ extern "C" int ptycho_cg_argmax(ptycho_handle h, int slot, void* best, void* str
     if (slot < 0 || slot > 1 || !h->work[slot]) return fail(PTYCHO_ERR_ARG, "work slot is empty");
     hipStream_t st = (hipStream_t)stream;
     PTY_DISPATCH(h->ge.ndet, (do_cg_argmax<NN>(h, slot, (unsigned long long*)best, st)));
+}
+
+extern "C" int ptycho_cg_zoom(ptycho_handle h, const void* image_product, const void* px, const void* py,
+                              const void* vt, const void* lz, int nc, int ups, void* best, void* stream) {
+    int rc = check_handle(h);
+    if (rc) return rc;
+    if (!image_product || !px || !py || !vt || !lz || !best) return fail(PTYCHO_ERR_ARG, "null operand");
+    const int N = h->ge.ndet;
+    const int nthreads = N > 256 ? N : 256;
+    if (N % 16 != 0 || N > 1024) return fail(PTYCHO_ERR_ARG, "zoomed DFT kernel needs ndet %% 16 == 0 and ndet <= 1024");
+    if (ups < 1 || ups > nthreads || nc < 0 || nc > kZoomRK) return fail(PTYCHO_ERR_ARG, "zoomed DFT window or rank split out of range");
+    const int npos = h->ge.ptheta * h->ge.nscan;
+    hipStream_t st = (hipStream_t)stream;
+    {
+        ProfSpan ps(h, K_ZOOM, st);
+        const c32* ip = (const c32*)image_product;
+        const double2 *ppx = (const double2*)px, *ppy = (const double2*)py;
+        const double *pv = (const double*)vt, *pl = (const double*)lz;
+        static const bool no_mfma = std::getenv("PTYCHO_HIP_ZOOM_SCALAR") != nullptr;   // comparison knob
+        if (N % 64 == 0 && !no_mfma) {
+            if (N <= 256)
+                hipLaunchKernelGGL((k_zoom_mfma<256>), dim3((unsigned)npos), dim3(256), 0, st, ip, ppx, ppy, pv, pl, N, nc, ups, (int*)best);
+            else if (N <= 512)
+                hipLaunchKernelGGL((k_zoom_mfma<512>), dim3((unsigned)npos), dim3(512), 0, st, ip, ppx, ppy, pv, pl, N, nc, ups, (int*)best);
+            else
+                hipLaunchKernelGGL((k_zoom_mfma<1024>), dim3((unsigned)npos), dim3(1024), 0, st, ip, ppx, ppy, pv, pl, N, nc, ups, (int*)best);
+        } else if (N <= 256)
+            hipLaunchKernelGGL((k_zoom_argmax<256, 8>), dim3((unsigned)npos), dim3(256), (size_t)N * 8 * sizeof(double2), st,
+                               ip, ppx, ppy, pv, pl, N, nc, ups, (int*)best);
+        else if (N <= 512)
+            hipLaunchKernelGGL((k_zoom_argmax<512, 4>), dim3((unsigned)npos), dim3(512), (size_t)N * 4 * sizeof(double2), st,
+                               ip, ppx, ppy, pv, pl, N, nc, ups, (int*)best);
+        else
+            hipLaunchKernelGGL((k_zoom_argmax<1024, 2>), dim3((unsigned)npos), dim3(1024), (size_t)N * 2 * sizeof(double2), st,
+                               ip, ppx, ppy, pv, pl, N, nc, ups, (int*)best);
+    }
+    HIP_TRY(hipGetLastError());
+    return PTYCHO_OK;
 }

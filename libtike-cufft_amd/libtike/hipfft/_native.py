@@ -9,7 +9,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libptychohip.so")
+LIB_PATH = os.environ.get("PTYCHO_HIP_LIB") or os.path.join(_HERE, "libptychohip.so")
 
 #: every symbol ``include/ptycho_hip.h`` declares
 SYMBOLS = ("ptycho_create", "ptycho_free", "ptycho_destroy", "ptycho_get",
@@ -19,7 +19,7 @@ SYMBOLS = ("ptycho_create", "ptycho_free", "ptycho_destroy", "ptycho_get",
            "ptycho_cg_adj_cols", "ptycho_cg_linesearch",
            "ptycho_cg_accum_intensity", "ptycho_cg_array_stats", "ptycho_cg_project_multi",
            "ptycho_cg_accum_terms", "ptycho_cg_array_costs",
-           "ptycho_cg_cross", "ptycho_cg_argmax",
+           "ptycho_cg_cross", "ptycho_cg_argmax", "ptycho_cg_zoom",
            "ptycho_last_error", "ptycho_version")
 
 if not os.path.exists(LIB_PATH):
@@ -60,6 +60,7 @@ cg_accum_terms = _sig("ptycho_cg_accum_terms", _i, _vp, _i, _i, _vp, _vp, _vp, _
 cg_array_costs = _sig("ptycho_cg_array_costs", _i, _vp, _vp, _vp, _vp, _vp, ctypes.c_double, _i, _vp, _vp)
 cg_cross = _sig("ptycho_cg_cross", _i, _vp, _i, _i, ctypes.c_double, _vp, _vp)
 cg_argmax = _sig("ptycho_cg_argmax", _i, _vp, _i, _vp, _vp)
+cg_zoom = _sig("ptycho_cg_zoom", _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp)
 profile = _sig("ptycho_profile", _i, _vp, _i)
 profile_read = _sig("ptycho_profile_read", _i, _vp, ctypes.POINTER(ctypes.c_double),
                     ctypes.POINTER(_ll), _i)
@@ -67,7 +68,7 @@ KERNEL_NAMES = ("k_cols<FWD>", "k_rows<fwd>", "k_rows<inv>", "k_cols<ADJ_OBJ>",
                 "k_cols<ADJ_PRB>", "k_cols<PLAIN>", "sort_positions",
                 "k_rows_fused<STATS>", "k_rows_fused<PROJECT>", "k_rows_fused<LINESEARCH>",
                 "k_fwd_team", "k_rows_fused<ACCUM>", "k_array_reduce",
-                "k_rows_fused<CROSS>", "k_cols_argmax")
+                "k_rows_fused<CROSS>", "k_cols_argmax", "k_zoom_argmax")
 last_error = _sig("ptycho_last_error", ctypes.c_char_p)
 version = _sig("ptycho_version", ctypes.c_char_p)
 

@@ -324,16 +324,78 @@ def _dy_direction(i, grad, grad0, d):
 # ---------------------------------------------------------------------------
 # position registration (ptycho.py:163-248)
 # ---------------------------------------------------------------------------
+_ZOOM_CACHE = {}
+
+
+def _zoom_factors(npts, ups, upsample_factor, sgn, device):
+    """Rank-revealing factorisation ``A = L @ R`` of the zoomed-DFT matrix
+    ``A[j, k] = exp(sgn 2 pi i j f_k)``, ``j < ups``, ``f = fftfreq(npts, upsample_factor)``.
+
+    The phase ``2 pi j f_k`` spans only a few radians over the whole matrix (the window is
+    1.5 detector pixels wide), so ``A`` is numerically low rank: for 150 x 256 at
+    ``upsample_factor = 100`` the singular values fall below 1e-15 of the largest after 16
+    terms.  Keeping every term above 1e-16 (plus two) reproduces ``A`` to float64 rounding --
+    the same error level as the summation order of a float64 GEMM -- with ~10x fewer
+    multiply-adds in the two contractions."""
+    key = (npts, ups, upsample_factor, sgn, str(device))
+    hit = _ZOOM_CACHE.get(key)
+    if hit is None:
+        freq = np.fft.fftfreq(npts, upsample_factor)
+        A = np.exp(sgn * 2j * np.pi * np.arange(ups)[:, None] * freq[None, :])
+        u, sv, vh = np.linalg.svd(A, full_matrices=False)
+        rank = min(int((sv > 1e-16 * sv[0]).sum()) + 2, len(sv))
+        if rank * 2 > len(sv):                       # not low rank (tiny detectors): keep A itself
+            L, R = np.eye(ups, dtype=np.complex128), A
+        else:
+            L, R = u[:, :rank] * sv[:rank], vh[:rank]
+        hit = (torch.as_tensor(np.ascontiguousarray(L), device=device),
+               torch.as_tensor(np.ascontiguousarray(R), device=device))
+        _ZOOM_CACHE[key] = hit
+    return hit
+
+
+def _zoom_real_factors(npts, ups, upsample_factor, device, rk=16):
+    """Real low-rank factors of the centred window kernel for the fused zoom kernel
+    (C ABI ``ptycho_cg_zoom``): with ``th = 2 pi fftfreq(npts, upsample_factor)`` and
+    ``jc = j - (ups-1)/2``, ``cos(jc th) = Lc Vc`` and ``sin(jc th) = Ls Vs``.  Returns
+    ``(vt [npts, rk], lz [ups, rk], nc)`` with the cos terms in columns ``< nc``, or ``None``
+    when more than ``rk`` terms are above 1e-15 of the largest singular value (the float64
+    noise floor of the kernel values themselves is ~1e-14: the phase argument reaches
+    hundreds of radians)."""
+    key = ("real", npts, ups, upsample_factor, rk, str(device))
+    if key in _ZOOM_CACHE:
+        return _ZOOM_CACHE[key]
+    th = 2.0 * np.pi * np.fft.fftfreq(npts, upsample_factor)
+    jc = np.arange(ups) - (ups - 1) / 2.0
+    arg = jc[:, None] * th[None, :]
+    uc, sc, vc = np.linalg.svd(np.cos(arg), full_matrices=False)
+    us, ss, vs = np.linalg.svd(np.sin(arg), full_matrices=False)
+    s0 = max(sc[0], ss[0] if len(ss) else 0.0)
+    ns = int((ss > 1e-15 * s0).sum())
+    ncos = int((sc > 1e-15 * s0).sum())
+    hit = None
+    if ncos + ns <= rk and rk - ns <= len(sc):
+        nc = rk - ns                                   # spare terms go to the cos part
+        lz = np.concatenate([uc[:, :nc] * sc[:nc], us[:, :ns] * ss[:ns]], axis=1)
+        vt = np.concatenate([vc[:nc], vs[:ns]], axis=0).T
+        hit = (torch.as_tensor(np.ascontiguousarray(vt), device=device),
+               torch.as_tensor(np.ascontiguousarray(lz), device=device), nc)
+    _ZOOM_CACHE[key] = hit
+    return hit
+
+
 def _upsampled_dft_batch(data, ups, upsample_factor, axis_offsets, conj=False):
     """Two matrix-multiply DFTs on an ``ups x ups`` window (``ptycho.py:163-188``).
 
     The reference builds a ``[nscan, ups, ndet]`` complex128 kernel per axis,
     ``exp(-2 pi i (j - off_i) f_k)``, and contracts it with ``einsum('ijk,ipk->ijp')``.
     The kernel factors as ``A[j,k] * B[i,k]`` with ``A = exp(-2 pi i j f_k)`` shared by all
-    patterns and ``B = exp(+2 pi i off_i f_k)`` a per-pattern phase, so each contraction is
-    one dense GEMM with ``A`` after an elementwise phase multiply -- same float64 math,
-    no 2.5 GB kernel tensors.  The contraction itself stays torch linear algebra
-    (SURVEY.md section 2, C7).
+    patterns and ``B = exp(+2 pi i off_i f_k)`` a per-pattern phase, and ``A`` itself is
+    numerically low rank (``_zoom_factors``: ``A = L R``).  Each contraction is therefore an
+    elementwise phase multiply and a dense GEMM with the thin factor ``R``; the ``ups x ups``
+    window is expanded from the small core at the end.  Same float64 math, no 2.5 GB kernel
+    tensors, ~10x fewer flops.  The contractions stay torch linear algebra (SURVEY.md
+    section 2, C7).
 
     ``conj=True`` returns ``conj(_upsampled_dft_batch(conj(data), ...))`` -- what the caller
     at ``ptycho.py:225-228`` actually needs -- by conjugating the (small) phase factors
@@ -341,21 +403,23 @@ def _upsampled_dft_batch(data, ups, upsample_factor, axis_offsets, conj=False):
     nb, nrow, ncol = data.shape
     dev = data.device
     sgn = 1.0 if conj else -1.0
-    freq = torch.fft.fftfreq(ncol, upsample_factor, dtype=torch.float64, device=dev)
-    j = torch.arange(ups, dtype=torch.float64, device=dev)
-    A = torch.exp(sgn * 2j * np.pi * (j[:, None] * freq[None, :]).to(torch.complex128))    # [ups, ncol]
+    Lc, Rc = _zoom_factors(ncol, ups, upsample_factor, sgn, dev)     # columns (k)
+    Lr, Rr = _zoom_factors(nrow, ups, upsample_factor, sgn, dev)     # rows (p)
 
-    def phase(off):                                                                        # [nb, ncol]
+    def phase(off, npts):                                            # [nb, npts]
+        freq = torch.fft.fftfreq(npts, upsample_factor, dtype=torch.float64, device=dev)
         return torch.exp(-sgn * 2j * np.pi * (off[:, None] * freq[None, :]).to(torch.complex128))
 
-    # first axis (columns, k): tmp[i, p, j] = sum_k A[j, k] B1[i, k] data[i, p, k]
+    # first axis (columns, k): tmp[i, p, r] = sum_k R[r, k] B1[i, k] data[i, p, k]
     # (complex64 x complex128 promotes inside the multiply: one pass, no separate cast)
-    x = torch.mul(data, phase(axis_offsets[:, 1])[:, None, :])                        # [nb, p, k] c128
-    tmp = torch.matmul(x, A.T)                                                        # [nb, p, j]
+    x = torch.mul(data, phase(axis_offsets[:, 1], ncol)[:, None, :])                 # [nb, p, k] c128
+    tmp = torch.matmul(x, Rc.T)                                                      # [nb, p, r]
     del x
-    # second axis (rows, p): rec[i, j2, j] = sum_p A[j2, p] B0[i, p] tmp[i, p, j]
-    tmp.mul_(phase(axis_offsets[:, 0])[:, :, None])
-    return torch.matmul(A, tmp)                                                       # [nb, j2, j]
+    # second axis (rows, p): core[i, r2, r] = sum_p R[r2, p] B0[i, p] tmp[i, p, r]
+    tmp.mul_(phase(axis_offsets[:, 0], nrow)[:, :, None])
+    core = torch.matmul(Rr, tmp)                                                     # [nb, r2, r]
+    # rec[i, j2, j] = sum L[j2, r2] core[i, r2, r] L[j, r]
+    return torch.matmul(torch.matmul(Lr, core), Lc.T)                                # [nb, j2, j]
 
 
 def _argmax2d(a):
@@ -364,9 +428,35 @@ def _argmax2d(a):
     return torch.stack((flat // w, flat % w), dim=1)
 
 
-def _finish_registration(image_product, maxima, upsample_factor):
+def _zoom_argmax_native(op, image_product, region, upsample_factor, offset):
+    """``argmax |conj(upsampled_dft(conj(image_product)))|`` per pattern through the fused
+    HIP kernel (``ptycho_cg_zoom``); ``None`` if the kernel does not cover this case."""
+    nb, nrow, ncol = image_product.shape
+    if (op is None or nrow != ncol or nrow != op.ndet or nb != op.ptheta * op.nscan
+            or nrow % 16 or nrow > 1024 or region > max(256, nrow)
+            or image_product.dtype != torch.complex64 or not image_product.is_contiguous()):
+        return None
+    dev = image_product.device
+    fac = _zoom_real_factors(nrow, region, upsample_factor, dev)
+    if fac is None:
+        return None
+    vt, lz, nc = fac
+    theta = 2.0 * np.pi * torch.fft.fftfreq(nrow, upsample_factor, dtype=torch.float64, device=dev)
+    c0 = (region - 1) / 2.0
+    ay, ax = theta[None, :] * (c0 - offset[:, 0:1]), theta[None, :] * (c0 - offset[:, 1:2])
+    py = torch.complex(torch.cos(ay), torch.sin(ay)).contiguous()
+    px = torch.complex(torch.cos(ax), torch.sin(ax)).contiguous()
+    best = torch.empty(nb, dtype=torch.int32, device=dev)
+    nat.check(nat.cg_zoom(op._h, _ptr(image_product), _ptr(px), _ptr(py), _ptr(vt), _ptr(lz), nc, region,
+                          _ptr(best), _stream()))
+    flat = best.to(torch.int64)
+    return torch.stack((flat // region, flat % region), dim=1)
+
+
+def _finish_registration(image_product, maxima, upsample_factor, op=None):
     """Second half of ``register_translation_batch`` (``ptycho.py:209-248``): wrap the
-    whole-pixel maxima, then the zoomed matrix DFT around them."""
+    whole-pixel maxima, then the zoomed matrix DFT around them (fused HIP kernel when ``op``
+    is given and covers the case, torch GEMMs otherwise)."""
     shape = image_product.shape
     mid = [float(np.fix(s / 2)) for s in shape[1:]]
     shifts = maxima.to(torch.float64)
@@ -380,8 +470,11 @@ def _finish_registration(image_product, maxima, upsample_factor):
         offset = dftshift - shifts * upsample_factor
         # = conj(upsampled_dft(conj(image_product))) / normalization of ptycho.py:225-229; the
         # positive normalisation does not move the arg-max and is skipped
-        cross = _upsampled_dft_batch(image_product, region, upsample_factor, offset, conj=True)
-        maxima = _argmax2d(torch.abs(cross)).to(torch.float64) - dftshift
+        peak = _zoom_argmax_native(op, image_product, region, upsample_factor, offset)
+        if peak is None:
+            cross = _upsampled_dft_batch(image_product, region, upsample_factor, offset, conj=True)
+            peak = _argmax2d(torch.abs(cross))
+        maxima = peak.to(torch.float64) - dftshift
         shifts = shifts + maxima / upsample_factor
     for dim in range(image_product.ndim):          # reference quirk, ptycho.py:243-245
         if shape[dim] == 1:
@@ -479,30 +572,42 @@ class CGPtychoSolver(PtychoHIP):
         nat.check(nat.cg_argmax(self._h, 1, _ptr(best), _stream()))
         idx = 0xffffffff - (best & 0xffffffff)
         maxima = torch.stack((idx // self.ndet, idx % self.ndet), dim=1)
-        return _finish_registration(ip, maxima, 100)
+        return _finish_registration(ip, maxima, 100, op=self)
 
-    def _fused_line_search(self, data, ab, costs):
-        """All trials of ``line_search_sqr`` (ptycho.py:253-281) for 16 step lengths per
+    def _fused_line_search(self, data, ab, costs, which="psi"):
+        """All trials of ``line_search_sqr`` (ptycho.py:253-281), up to 16 step lengths per
         pass over the two work buffers (p1, p2, p3 never leave registers); returns the
-        accepted step length (0 on failure).  Measured alternative: writing the terms out once
-        and pricing 32 steps per pass from arrays is not faster -- each trial step costs
-        ~0.12 ms of sqrt/FMA work at 4096 x 256^2 wherever it is evaluated."""
+        accepted step length (0 on failure).  Every step length before the accepted one is
+        still evaluated and rejected, as in the reference; only the number priced per pass
+        adapts: the accepted index moves slowly from one iteration to the next, so a pass
+        prices two more than the last accepted index of the same search (``which``) and a
+        second pass continues from there if none is accepted.  Measured alternative:
+        writing the terms out once and pricing 32 steps per pass from arrays is not faster
+        -- each trial step costs ~0.06 ms of sqrt/FMA work at 4096 x 256^2 wherever it is
+        evaluated."""
+        hints = self.__dict__.setdefault("_ls_hint", {})
+        ncand = min(16, max(2, hints.get(which, 14) + 2))
         gamma0 = 1.0
+        tried = 0
         while True:
             costs.zero_()
             nat.check(nat.cg_linesearch(self._h, 0, 1, _ptr(data), _ptr(ab) if ab is not None else None,
-                                        gamma0, 16, _ptr(costs), _stream()))
+                                        gamma0, ncand, _ptr(costs), _stream()))
             self._allreduce(costs)
             c = costs.to(torch.float32).cpu().numpy()      # the reference compares float32 costs
             step = gamma0
-            for j in range(16):
-                if not (c[j] > c[16]):
+            for j in range(ncand):
+                if not (c[j] > c[ncand]):
+                    hints[which] = tried + j
                     return step
                 if step < 1e-32:
                     warnings.warn("Line search failed for conjugate gradient.")
+                    hints[which] = 14
                     return 0
                 step *= 0.5
             gamma0 = step
+            tried += ncand
+            ncand = 16
 
     def _run_fused(self, data, psi, scan, probe, piter, recover_prb):
         """``CGPtychoSolver.run`` (ptycho.py:283-488) for one probe mode and the gaussian
@@ -563,7 +668,7 @@ class CGPtychoSolver(PtychoHIP):
                 dprb = _dy_direction(i, gradprb, gradprb0, dprb)
                 gradprb0 = gradprb
                 self._cg_fwd_cols(1, psi, scan, dprb[:, 0].contiguous())
-                gammaprb = 0.5 * self._fused_line_search(data, None, costs)
+                gammaprb = 0.5 * self._fused_line_search(data, None, costs, which="prb")
                 probe[:, 0] = probe[:, 0] + gammaprb * dprb[:, 0]
 
             if i % self.log_every == 0:

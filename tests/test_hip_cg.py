@@ -175,3 +175,39 @@ def test_registration_recovers_known_shift(pt):
                                          100, "fourier").cpu().numpy()
     np.testing.assert_allclose(got, -true, atol=0.011)
     np.testing.assert_allclose(got, want, atol=0.011)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ndet", [32, 64, 256])
+def test_zoom_kernel_matches_torch_contraction(ndet):
+    """Fused zoomed DFT + arg-max (``ptycho_cg_zoom``, real low-rank window kernel) against
+    the torch GEMM restatement of ``ptycho.py:163-188`` and against the oracle's einsum."""
+    import torch
+    from libtike.hipfft import ptycho as P
+    from oracle import cg_oracle as co
+    nscan = 37
+    rng = np.random.default_rng(5)
+    with P.CGPtychoSolver(nscan, ndet, ndet, 1, ndet + 8, ndet + 8) as slv:
+        # smooth correlation peak near a random sub-pixel shift + noise
+        ky = np.fft.fftfreq(ndet)[None, :, None]
+        kx = np.fft.fftfreq(ndet)[None, None, :]
+        true = rng.uniform(-3, 3, (nscan, 2))
+        base = rng.standard_normal((nscan, ndet, ndet)) ** 2 + 0.1
+        ip = base * np.exp(-2j * np.pi * (ky * true[:, 0, None, None] + kx * true[:, 1, None, None]))
+        ip = (ip + 0.05 * (rng.standard_normal(ip.shape) + 1j * rng.standard_normal(ip.shape))).astype(np.complex64)
+        coarse = np.round(true * 100) / 100
+        coarse = np.round(coarse)                      # whole-pixel stage result
+        off = 75.0 - coarse * 100
+        dip = torch.as_tensor(ip, device="cuda")
+        doff = torch.as_tensor(off, device="cuda")
+        got = P._zoom_argmax_native(slv, dip, 150, 100, doff)
+        assert got is not None, "native zoom kernel declined a case it should cover"
+        cross = P._upsampled_dft_batch(dip, 150, 100, doff, conj=True)
+        want = P._argmax2d(torch.abs(cross))
+        ref = np.conj(co.upsampled_dft_batch(np.conj(ip), 150, 100, off))
+        want_o = np.stack(np.unravel_index(np.abs(ref).reshape(nscan, -1).argmax(1), (150, 150)), axis=1)
+        np.testing.assert_array_equal(want.cpu().numpy(), want_o)
+        np.testing.assert_array_equal(got.cpu().numpy(), want_o)
+        # and the sub-pixel shift it implies is the true one to the grid resolution
+        shift = coarse + (got.cpu().numpy() - 75.0) / 100
+        assert np.abs(shift - true).max() < 0.02
