@@ -127,17 +127,21 @@ int ptycho_cg_cross(ptycho_handle h, int slot1, int slot2, double gamma, void* i
                     void* stream);
 int ptycho_cg_argmax(ptycho_handle h, int slot, void* best, void* stream);
 
-/* Sub-pixel stage of the registration (ptycho.py:163-188, 217-235): zoomed matrix DFT of the
- * image product on an ups x ups window around each whole-pixel peak with a fused arg-max,
- *   cross[i,j2,j1] = sum_p sum_k py[i,p] K[j2,p] ip[i,p,k] px[i,k] K[j1,k],  best[i] = argmax |cross[i]|
- * (flat index j2 * ups + j1, first maximum).  px, py: complex128 [ptheta*nscan][ndet], the
- * per-pattern phases exp(+i th (c0 - offset)); the centred window kernel
- * K[j,k] = exp(+i th_k (j - c0)) is passed as real low-rank factors
- *   K = sum_{r<nc} lz[j,r] vt[k,r] + i sum_{r>=nc} lz[j,r] vt[k,r],
+/* Sub-pixel stage of the registration (ptycho.py:209-235): from the whole-pixel peaks
+ * (best = output of ptycho_cg_argmax; only the low word, 0xffffffff - flat index, is read)
+ * wrap the peak to [-ndet/2, ndet/2), then evaluate the zoomed matrix DFT of the image
+ * product on an ups x ups window around it (ups = ceil(1.5 upsample_factor)),
+ *   cross[i,j2,j1] = sum_p sum_k e^{+i th_p (j2 - offy_i)} e^{+i th_k (j1 - offx_i)} ip[i,p,k],
+ *   th = 2 pi fftfreq(ndet, upsample_factor),  off = fix(ups/2) - shift upsample_factor,
+ * take the first maximum of |cross[i]| and return
+ *   shifts[i] = shift + (argmax - fix(ups/2)) / upsample_factor     (float64 [ptheta*nscan][2]).
+ * The centred window kernel K[j,k] = exp(+i th_k (j - (ups-1)/2)) is passed as real low-rank
+ * factors  K = sum_{r<nc} lz[j,r] vt[k,r] + i sum_{r>=nc} lz[j,r] vt[k,r],
  * vt: float64 [ndet][16], lz: float64 [ups][16] (cos terms first, then sin terms).
- * Needs ndet % 16 == 0, ndet <= 1024, ups <= max(256, ndet).  best: int32 [ptheta*nscan]. */
-int ptycho_cg_zoom(ptycho_handle h, const void* image_product, const void* px, const void* py,
-                   const void* vt, const void* lz, int nc, int ups, void* best, void* stream);
+ * Needs ndet % 16 == 0, ndet <= 1024, ups <= max(256, ndet). */
+int ptycho_cg_zoom(ptycho_handle h, const void* image_product, const void* best, const void* vt,
+                   const void* lz, int nc, int ups, double upsample_factor, void* shifts,
+                   void* stream);
 
 /* Tuning knobs: "chunk" (positions per launch pair, 0 = default);
  * "window" (1 = LDS overlap-add object adjoint [default], 0 = direct atomics);

@@ -204,8 +204,11 @@ __global__ __launch_bounds__(256) void k_rows_fused(const RowFusedArgs a) {
     fft.init(j0, a.table);
     const c32 zero = c32{0.0f, 0.0f};
     float acc[NACC];
+    c32 acc2[EP == EP_LINESEARCH ? NACC : 1];   // line search: even / odd pixel partial sums
 #pragma unroll
     for (int i = 0; i < NACC; ++i) acc[i] = 0.0f;
+#pragma unroll
+    for (int i = 0; i < (EP == EP_LINESEARCH ? NACC : 1); ++i) acc2[i] = c32{0.0f, 0.0f};
 
     // scale factors of ptycho.py:344-351 in float32, as the reference computes them
     float s = 1.0f, sinv = 1.0f;
@@ -357,27 +360,37 @@ __global__ __launch_bounds__(256) void k_rows_fused(const RowFusedArgs a) {
             fft.template load<0>(v, j0, [&](int i) { return (ok && i >= a.xa && i < a.xb) ? __builtin_nontemporal_load(a.s2 + rowoff + i) : zero; });
             fwd_row(v, g2);
             load_data();   // after the second transform: keeps 16 registers free during it
+            // two detector pixels per step in packed float32 (v_pk_fma_f32 / v_pk_add_f32), four
+            // step lengths per uniform branch: per trial and pixel 2 FMA for p1 + y^2 p2 + y p3,
+            // one v_sqrt_f32, one subtract, one FMA into the cost
 #pragma unroll
-            for (int m = 0; m < E; ++m) {
-                const c32 t1 = g1[m] * s;
-                const float p1 = t1.x * t1.x + t1.y * t1.y;
-                const float p2 = g2[m].x * g2[m].x + g2[m].y * g2[m].y;
-                const float p3 = 2.0f * (t1.x * g2[m].x + t1.y * g2[m].y);
-                const float sd = fsqrt(d[m]);
-                float df = fsqrt(fabsf(p1)) - sd;
-                acc[kMaxCand] += df * df;
+            for (int m = 0; m < E; m += 2) {
+                const c32 ta = g1[m] * s, tb = g1[m + 1] * s;
+                const c32 p1 = c32{ta.x * ta.x + ta.y * ta.y, tb.x * tb.x + tb.y * tb.y};
+                const c32 p2 = c32{g2[m].x * g2[m].x + g2[m].y * g2[m].y, g2[m + 1].x * g2[m + 1].x + g2[m + 1].y * g2[m + 1].y};
+                const c32 p3 = c32{2.0f * (ta.x * g2[m].x + ta.y * g2[m].y), 2.0f * (tb.x * g2[m + 1].x + tb.y * g2[m + 1].y)};
+                const c32 sd = c32{fsqrt(d[m]), fsqrt(d[m + 1])};
+                c32 df = c32{fsqrt(fabsf(p1.x)), fsqrt(fabsf(p1.y))} - sd;
+                acc2[kMaxCand] += df * df;
                 float gam = a.gamma0;
 #pragma unroll
-                for (int j = 0; j < kMaxCand; ++j) {
-                    if (j < a.ncand) {
-                        const float xx = p1 + (gam * gam) * p2 + gam * p3;
-                        df = fsqrt(fabsf(xx)) - sd;
-                        acc[j] += df * df;
+                for (int j0c = 0; j0c < kMaxCand; j0c += 4) {
+                    if (j0c < a.ncand) {
+#pragma unroll
+                        for (int j = j0c; j < j0c + 4; ++j) {
+                            const c32 xx = p1 + p2 * (gam * gam) + p3 * gam;
+                            df = c32{fsqrt(fabsf(xx.x)), fsqrt(fabsf(xx.y))} - sd;
+                            acc2[j] += df * df;
+                            gam *= 0.5f;
+                        }
                     }
-                    gam *= 0.5f;
                 }
             }
         }
+    }
+    if (EP == EP_LINESEARCH) {
+#pragma unroll
+        for (int i = 0; i < NACC; ++i) acc[i] = acc2[i].x + acc2[i].y;
     }
     if (EP == EP_ACCUM_I || EP == EP_ACCUM_P || EP == EP_CROSS) return;
     // ---- block reduction (float partials -> double), one atomic per value per workgroup

@@ -27,7 +27,9 @@ template <int NT, int RKC>
 __global__ __launch_bounds__(NT) void k_zoom_argmax(const c32* __restrict__ ip, const double2* __restrict__ px,
                                                     const double2* __restrict__ py, const double* __restrict__ vt,
                                                     const double* __restrict__ lz, const int N, const int nc,
-                                                    const int ups, int* __restrict__ out) {
+                                                    const int ups, int* __restrict__ out,
+                                                    const double* __restrict__ coarse, const double up,
+                                                    double* __restrict__ shifts) {
     constexpr int RK = kZoomRK;
     constexpr int NW = NT / 64;
     extern __shared__ double2 ybuf[];          // [N][RKC]
@@ -148,7 +150,12 @@ __global__ __launch_bounds__(NT) void k_zoom_argmax(const c32* __restrict__ ip, 
 #pragma unroll
         for (int w = 1; w < NW; ++w)
             if (redv[w] > best || (redv[w] == best && redi[w] < besti)) { best = redv[w]; besti = redi[w]; }
-        out[i] = besti;
+        if (out) out[i] = besti;
+        if (shifts) {   // ptycho.py:233-235: shifts + (argmax - dftshift) / upsample_factor
+            const double dftshift = (double)(ups / 2);
+            shifts[2 * i] = coarse[2 * i] + ((double)(besti / ups) - dftshift) / up;
+            shifts[2 * i + 1] = coarse[2 * i + 1] + ((double)(besti % ups) - dftshift) / up;
+        }
     }
 }
 
@@ -168,11 +175,44 @@ __global__ __launch_bounds__(NT) void k_zoom_argmax(const c32* __restrict__ ip, 
 // ---------------------------------------------------------------------------
 typedef double zd4 __attribute__((ext_vector_type(4)));
 
+// ---------------------------------------------------------------------------
+// Whole-pixel peak -> offsets and phases (ptycho.py:209-224) for the zoom kernels.
+// best[i] is k_cols_argmax's packed result (low word = 0xffffffff - flat index).  The peak
+// row / column is wrapped to [-N/2, N/2) as register_translation does (index > N/2 -> - N),
+// coarse[i] = (sy, sx), and the per-pattern phases of the window kernel are
+//   p[i, k] = exp(+i th_k (c0 - off)),  th_k = 2 pi k' / (N up),  off = fix(ups/2) - s up,
+// c0 = (ups - 1) / 2; with an integer shift s the product k' s is reduced modulo N exactly.
+// ---------------------------------------------------------------------------
+__global__ void k_zoom_prepare(const unsigned long long* __restrict__ best, const int N, const int ups,
+                               const double up, double2* __restrict__ px, double2* __restrict__ py,
+                               double* __restrict__ coarse) {
+    const size_t i = blockIdx.x;
+    const unsigned idx = 0xffffffffu - (unsigned)(best[i] & 0xffffffffull);
+    int sy = (int)(idx / (unsigned)N), sx = (int)(idx % (unsigned)N);
+    if (sy > N / 2) sy -= N;
+    if (sx > N / 2) sx -= N;
+    if (threadIdx.x == 0) { coarse[2 * i] = (double)sy; coarse[2 * i + 1] = (double)sx; }
+    const double delta = 0.5 * (double)(ups - 1) - (double)(ups / 2);
+    for (int k = threadIdx.x; k < N; k += blockDim.x) {
+        const int kp = k < (N + 1) / 2 ? k : k - N;                       // fftfreq order
+        const double fine = delta * (double)kp / ((double)N * up);
+        const long long my = ((long long)kp * sy) % N, mx = ((long long)kp * sx) % N;
+        double sn, cs;
+        sincos(2.0 * M_PI * ((double)my / (double)N + fine), &sn, &cs);
+        py[i * N + k] = double2{cs, sn};
+        sincos(2.0 * M_PI * ((double)mx / (double)N + fine), &sn, &cs);
+        px[i * N + k] = double2{cs, sn};
+    }
+}
+
+
 template <int NT>
 __global__ __launch_bounds__(NT) void k_zoom_mfma(const c32* __restrict__ ip, const double2* __restrict__ px,
                                                   const double2* __restrict__ py, const double* __restrict__ vt,
                                                   const double* __restrict__ lz, const int N, const int nc,
-                                                  const int ups, int* __restrict__ out) {
+                                                  const int ups, int* __restrict__ out,
+                                                  const double* __restrict__ coarse, const double up,
+                                                  double* __restrict__ shifts) {
     constexpr int RK = kZoomRK;
     constexpr int NW = NT / 64;
     __shared__ double2 cpart[NW * RK * RK];
@@ -301,6 +341,11 @@ __global__ __launch_bounds__(NT) void k_zoom_mfma(const c32* __restrict__ ip, co
 #pragma unroll
         for (int ww = 1; ww < NW; ++ww)
             if (redv[ww] > best || (redv[ww] == best && redi[ww] < besti)) { best = redv[ww]; besti = redi[ww]; }
-        out[i] = besti;
+        if (out) out[i] = besti;
+        if (shifts) {   // ptycho.py:233-235: shifts + (argmax - dftshift) / upsample_factor
+            const double dftshift = (double)(ups / 2);
+            shifts[2 * i] = coarse[2 * i] + ((double)(besti / ups) - dftshift) / up;
+            shifts[2 * i + 1] = coarse[2 * i + 1] + ((double)(besti % ups) - dftshift) / up;
+        }
     }
 }

@@ -79,6 +79,7 @@ struct ptycho_handle_s {
     void* sort_tmp = nullptr;
     size_t sort_tmp_bytes = 0;
     c32* work[2] = {nullptr, nullptr};   // CG work buffers (column-pass intermediates), all positions
+    void* zoom_phase = nullptr;           // registration: per-pattern phases + whole-pixel shifts
     int use_window = 1;       // 0: direct-atomics object adjoint (k_cols<ADJ_OBJ>)
     int use_team = 0;         // 1: forward operator as one persistent XCD-team launch (experimental)
     int use_split = 1;        // ndet = 256: one radix-16 step of the DFT over y runs in the row pass
@@ -664,8 +665,8 @@ int alloc_sort(ptycho_handle h) {
 }
 
 void release(ptycho_handle h) {
-    void* ptrs[] = {h->table, h->scratch, h->keys_a, h->keys_b, h->vals_a, h->order, h->sort_tmp, h->work[0], h->work[1], h->ring, h->ctrl};
-    h->ring = nullptr; h->ctrl = nullptr;
+    void* ptrs[] = {h->table, h->scratch, h->keys_a, h->keys_b, h->vals_a, h->order, h->sort_tmp, h->work[0], h->work[1], h->ring, h->ctrl, h->zoom_phase};
+    h->ring = nullptr; h->ctrl = nullptr; h->zoom_phase = nullptr;
     h->work[0] = nullptr; h->work[1] = nullptr;
     for (void* q : ptrs)
         if (q) (void)hipFree(q);
@@ -1037,39 +1038,48 @@ extern "C" int ptycho_cg_argmax(ptycho_handle h, int slot, void* best, void* str
     PTY_DISPATCH(h->ge.ndet, (do_cg_argmax<NN>(h, slot, (unsigned long long*)best, st)));
 }
 
-extern "C" int ptycho_cg_zoom(ptycho_handle h, const void* image_product, const void* px, const void* py,
-                              const void* vt, const void* lz, int nc, int ups, void* best, void* stream) {
+extern "C" int ptycho_cg_zoom(ptycho_handle h, const void* image_product, const void* best, const void* vt,
+                              const void* lz, int nc, int ups, double upsample_factor, void* shifts, void* stream) {
     int rc = check_handle(h);
     if (rc) return rc;
-    if (!image_product || !px || !py || !vt || !lz || !best) return fail(PTYCHO_ERR_ARG, "null operand");
+    if (!image_product || !best || !vt || !lz || !shifts) return fail(PTYCHO_ERR_ARG, "null operand");
     const int N = h->ge.ndet;
     const int nthreads = N > 256 ? N : 256;
     if (N % 16 != 0 || N > 1024) return fail(PTYCHO_ERR_ARG, "zoomed DFT kernel needs ndet %% 16 == 0 and ndet <= 1024");
-    if (ups < 1 || ups > nthreads || nc < 0 || nc > kZoomRK) return fail(PTYCHO_ERR_ARG, "zoomed DFT window or rank split out of range");
+    if (ups < 1 || ups > nthreads || nc < 0 || nc > kZoomRK || !(upsample_factor >= 1.0))
+        return fail(PTYCHO_ERR_ARG, "zoomed DFT window, rank split or upsample factor out of range");
     const int npos = h->ge.ptheta * h->ge.nscan;
     hipStream_t st = (hipStream_t)stream;
+    if (!h->zoom_phase) {   // px, py: complex128 [npos][N] each; coarse shifts: float64 [npos][2]
+        HIP_TRY(hipMalloc(&h->zoom_phase, (size_t)npos * N * 2 * sizeof(double2) + (size_t)npos * 2 * sizeof(double)));
+    }
+    double2* ppx = (double2*)h->zoom_phase;
+    double2* ppy = ppx + (size_t)npos * N;
+    double* coarse = (double*)(ppy + (size_t)npos * N);
     {
         ProfSpan ps(h, K_ZOOM, st);
         const c32* ip = (const c32*)image_product;
-        const double2 *ppx = (const double2*)px, *ppy = (const double2*)py;
         const double *pv = (const double*)vt, *pl = (const double*)lz;
+        hipLaunchKernelGGL(k_zoom_prepare, dim3((unsigned)npos), dim3(N < 256 ? N : 256), 0, st,
+                           (const unsigned long long*)best, N, ups, upsample_factor, ppx, ppy, coarse);
         static const bool no_mfma = std::getenv("PTYCHO_HIP_ZOOM_SCALAR") != nullptr;   // comparison knob
+        int* none = nullptr;
         if (N % 64 == 0 && !no_mfma) {
             if (N <= 256)
-                hipLaunchKernelGGL((k_zoom_mfma<256>), dim3((unsigned)npos), dim3(256), 0, st, ip, ppx, ppy, pv, pl, N, nc, ups, (int*)best);
+                hipLaunchKernelGGL((k_zoom_mfma<256>), dim3((unsigned)npos), dim3(256), 0, st, ip, ppx, ppy, pv, pl, N, nc, ups, none, coarse, upsample_factor, (double*)shifts);
             else if (N <= 512)
-                hipLaunchKernelGGL((k_zoom_mfma<512>), dim3((unsigned)npos), dim3(512), 0, st, ip, ppx, ppy, pv, pl, N, nc, ups, (int*)best);
+                hipLaunchKernelGGL((k_zoom_mfma<512>), dim3((unsigned)npos), dim3(512), 0, st, ip, ppx, ppy, pv, pl, N, nc, ups, none, coarse, upsample_factor, (double*)shifts);
             else
-                hipLaunchKernelGGL((k_zoom_mfma<1024>), dim3((unsigned)npos), dim3(1024), 0, st, ip, ppx, ppy, pv, pl, N, nc, ups, (int*)best);
+                hipLaunchKernelGGL((k_zoom_mfma<1024>), dim3((unsigned)npos), dim3(1024), 0, st, ip, ppx, ppy, pv, pl, N, nc, ups, none, coarse, upsample_factor, (double*)shifts);
         } else if (N <= 256)
             hipLaunchKernelGGL((k_zoom_argmax<256, 8>), dim3((unsigned)npos), dim3(256), (size_t)N * 8 * sizeof(double2), st,
-                               ip, ppx, ppy, pv, pl, N, nc, ups, (int*)best);
+                               ip, ppx, ppy, pv, pl, N, nc, ups, none, coarse, upsample_factor, (double*)shifts);
         else if (N <= 512)
             hipLaunchKernelGGL((k_zoom_argmax<512, 4>), dim3((unsigned)npos), dim3(512), (size_t)N * 4 * sizeof(double2), st,
-                               ip, ppx, ppy, pv, pl, N, nc, ups, (int*)best);
+                               ip, ppx, ppy, pv, pl, N, nc, ups, none, coarse, upsample_factor, (double*)shifts);
         else
             hipLaunchKernelGGL((k_zoom_argmax<1024, 2>), dim3((unsigned)npos), dim3(1024), (size_t)N * 2 * sizeof(double2), st,
-                               ip, ppx, ppy, pv, pl, N, nc, ups, (int*)best);
+                               ip, ppx, ppy, pv, pl, N, nc, ups, none, coarse, upsample_factor, (double*)shifts);
     }
     HIP_TRY(hipGetLastError());
     return PTYCHO_OK;

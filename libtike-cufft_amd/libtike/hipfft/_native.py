@@ -60,7 +60,7 @@ cg_accum_terms = _sig("ptycho_cg_accum_terms", _i, _vp, _i, _i, _vp, _vp, _vp, _
 cg_array_costs = _sig("ptycho_cg_array_costs", _i, _vp, _vp, _vp, _vp, _vp, ctypes.c_double, _i, _vp, _vp)
 cg_cross = _sig("ptycho_cg_cross", _i, _vp, _i, _i, ctypes.c_double, _vp, _vp)
 cg_argmax = _sig("ptycho_cg_argmax", _i, _vp, _i, _vp, _vp)
-cg_zoom = _sig("ptycho_cg_zoom", _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp)
+cg_zoom = _sig("ptycho_cg_zoom", _i, _vp, _vp, _vp, _vp, _vp, _i, _i, ctypes.c_double, _vp, _vp)
 profile = _sig("ptycho_profile", _i, _vp, _i)
 profile_read = _sig("ptycho_profile_read", _i, _vp, ctypes.POINTER(ctypes.c_double),
                     ctypes.POINTER(_ll), _i)

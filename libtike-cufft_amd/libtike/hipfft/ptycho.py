@@ -428,12 +428,15 @@ def _argmax2d(a):
     return torch.stack((flat // w, flat % w), dim=1)
 
 
-def _zoom_argmax_native(op, image_product, region, upsample_factor, offset):
-    """``argmax |conj(upsampled_dft(conj(image_product)))|`` per pattern through the fused
-    HIP kernel (``ptycho_cg_zoom``); ``None`` if the kernel does not cover this case."""
+def _zoom_shifts_native(op, image_product, best, upsample_factor):
+    """Sub-pixel stage of the registration through the fused HIP kernels
+    (``ptycho_cg_zoom``): ``best`` holds the whole-pixel peaks in ``ptycho_cg_argmax``'s packed
+    form (int64, low word ``0xffffffff - flat index``); returns the float64 ``[nb, 2]`` shifts
+    of ``ptycho.py:209-235``, or ``None`` if the kernels do not cover this case."""
     nb, nrow, ncol = image_product.shape
+    region = int(np.ceil(upsample_factor * 1.5))
     if (op is None or nrow != ncol or nrow != op.ndet or nb != op.ptheta * op.nscan
-            or nrow % 16 or nrow > 1024 or region > max(256, nrow)
+            or nrow % 16 or nrow > 1024 or region > max(256, nrow) or upsample_factor < 1
             or image_product.dtype != torch.complex64 or not image_product.is_contiguous()):
         return None
     dev = image_product.device
@@ -441,23 +444,22 @@ def _zoom_argmax_native(op, image_product, region, upsample_factor, offset):
     if fac is None:
         return None
     vt, lz, nc = fac
-    theta = 2.0 * np.pi * torch.fft.fftfreq(nrow, upsample_factor, dtype=torch.float64, device=dev)
-    c0 = (region - 1) / 2.0
-    ay, ax = theta[None, :] * (c0 - offset[:, 0:1]), theta[None, :] * (c0 - offset[:, 1:2])
-    py = torch.complex(torch.cos(ay), torch.sin(ay)).contiguous()
-    px = torch.complex(torch.cos(ax), torch.sin(ax)).contiguous()
-    best = torch.empty(nb, dtype=torch.int32, device=dev)
-    nat.check(nat.cg_zoom(op._h, _ptr(image_product), _ptr(px), _ptr(py), _ptr(vt), _ptr(lz), nc, region,
-                          _ptr(best), _stream()))
-    flat = best.to(torch.int64)
-    return torch.stack((flat // region, flat % region), dim=1)
+    shifts = torch.empty((nb, 2), dtype=torch.float64, device=dev)
+    nat.check(nat.cg_zoom(op._h, _ptr(image_product), _ptr(best), _ptr(vt), _ptr(lz), nc, region,
+                          float(upsample_factor), _ptr(shifts), _stream()))
+    return shifts
 
 
 def _finish_registration(image_product, maxima, upsample_factor, op=None):
     """Second half of ``register_translation_batch`` (``ptycho.py:209-248``): wrap the
-    whole-pixel maxima, then the zoomed matrix DFT around them (fused HIP kernel when ``op``
+    whole-pixel maxima, then the zoomed matrix DFT around them (fused HIP kernels when ``op``
     is given and covers the case, torch GEMMs otherwise)."""
     shape = image_product.shape
+    if upsample_factor > 1 and op is not None:
+        packed = 0xffffffff - (maxima[:, 0].to(torch.int64) * shape[2] + maxima[:, 1].to(torch.int64))
+        shifts = _zoom_shifts_native(op, image_product, packed.contiguous(), upsample_factor)
+        if shifts is not None:
+            return shifts
     mid = [float(np.fix(s / 2)) for s in shape[1:]]
     shifts = maxima.to(torch.float64)
     shifts[:, 0] = torch.where(shifts[:, 0] > mid[0], shifts[:, 0] - shape[1], shifts[:, 0])
@@ -466,15 +468,11 @@ def _finish_registration(image_product, maxima, upsample_factor, op=None):
         shifts = torch.round(shifts * upsample_factor) / upsample_factor
         region = int(np.ceil(upsample_factor * 1.5))
         dftshift = float(np.fix(region / 2.0))
-        normalization = shape[1] * shape[2] * upsample_factor ** 2
         offset = dftshift - shifts * upsample_factor
         # = conj(upsampled_dft(conj(image_product))) / normalization of ptycho.py:225-229; the
         # positive normalisation does not move the arg-max and is skipped
-        peak = _zoom_argmax_native(op, image_product, region, upsample_factor, offset)
-        if peak is None:
-            cross = _upsampled_dft_batch(image_product, region, upsample_factor, offset, conj=True)
-            peak = _argmax2d(torch.abs(cross))
-        maxima = peak.to(torch.float64) - dftshift
+        cross = _upsampled_dft_batch(image_product, region, upsample_factor, offset, conj=True)
+        maxima = _argmax2d(torch.abs(cross)).to(torch.float64) - dftshift
         shifts = shifts + maxima / upsample_factor
     for dim in range(image_product.ndim):          # reference quirk, ptycho.py:243-245
         if shape[dim] == 1:
@@ -559,7 +557,9 @@ class CGPtychoSolver(PtychoHIP):
         """Shifts of ptycho.py:398-403.  Fused form (one angle): column passes of
         fwd(psi, 1) and fwd(dpsi, 1), one row pass that forms u1 conj(u1 + gamma u2) and its
         inverse row DFT, one column pass with a fused arg-max; then the zoomed DFT."""
-        ones = probe[:, 0] * 0 + 1
+        ones = self.__dict__.get("_ones_probe")
+        if ones is None or ones.shape != probe[:, 0].shape or ones.device != probe.device:
+            ones = self._ones_probe = torch.ones_like(probe[:, 0])
         if not (self.fused and self.ptheta == 1):
             tmp1 = self.fwd(psi, scan, ones)[0]
             tmp2 = self.fwd(psi + gammapsi * dpsi, scan, ones)[0]
@@ -570,9 +570,12 @@ class CGPtychoSolver(PtychoHIP):
         nat.check(nat.cg_cross(self._h, 0, 1, float(gammapsi), _ptr(ip), _stream()))
         best = torch.empty(self.nscan, dtype=torch.int64, device=psi.device)
         nat.check(nat.cg_argmax(self._h, 1, _ptr(best), _stream()))
+        shifts = _zoom_shifts_native(self, ip, best, 100)
+        if shifts is not None:
+            return shifts
         idx = 0xffffffff - (best & 0xffffffff)
         maxima = torch.stack((idx // self.ndet, idx % self.ndet), dim=1)
-        return _finish_registration(ip, maxima, 100, op=self)
+        return _finish_registration(ip, maxima, 100)
 
     def _fused_line_search(self, data, ab, costs, which="psi"):
         """All trials of ``line_search_sqr`` (ptycho.py:253-281), up to 16 step lengths per

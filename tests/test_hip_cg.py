@@ -180,8 +180,9 @@ def test_registration_recovers_known_shift(pt):
 @pytest.mark.gpu
 @pytest.mark.parametrize("ndet", [32, 64, 256])
 def test_zoom_kernel_matches_torch_contraction(ndet):
-    """Fused zoomed DFT + arg-max (``ptycho_cg_zoom``, real low-rank window kernel) against
-    the torch GEMM restatement of ``ptycho.py:163-188`` and against the oracle's einsum."""
+    """Fused sub-pixel registration stage (``ptycho_cg_zoom``: peak wrap, phases, real
+    low-rank zoomed DFT on the float64 matrix cores, arg-max) against the torch GEMM
+    restatement of ``ptycho.py:163-188,209-235`` and against the oracle's einsum."""
     import torch
     from libtike.hipfft import ptycho as P
     from oracle import cg_oracle as co
@@ -195,19 +196,20 @@ def test_zoom_kernel_matches_torch_contraction(ndet):
         base = rng.standard_normal((nscan, ndet, ndet)) ** 2 + 0.1
         ip = base * np.exp(-2j * np.pi * (ky * true[:, 0, None, None] + kx * true[:, 1, None, None]))
         ip = (ip + 0.05 * (rng.standard_normal(ip.shape) + 1j * rng.standard_normal(ip.shape))).astype(np.complex64)
-        coarse = np.round(true * 100) / 100
-        coarse = np.round(coarse)                      # whole-pixel stage result
+        coarse = np.round(true)                        # whole-pixel stage result
+        maxima = np.where(coarse < 0, coarse + ndet, coarse).astype(np.int64)   # unwrapped peak indices
         off = 75.0 - coarse * 100
-        dip = torch.as_tensor(ip, device="cuda")
-        doff = torch.as_tensor(off, device="cuda")
-        got = P._zoom_argmax_native(slv, dip, 150, 100, doff)
-        assert got is not None, "native zoom kernel declined a case it should cover"
-        cross = P._upsampled_dft_batch(dip, 150, 100, doff, conj=True)
-        want = P._argmax2d(torch.abs(cross))
         ref = np.conj(co.upsampled_dft_batch(np.conj(ip), 150, 100, off))
-        want_o = np.stack(np.unravel_index(np.abs(ref).reshape(nscan, -1).argmax(1), (150, 150)), axis=1)
-        np.testing.assert_array_equal(want.cpu().numpy(), want_o)
-        np.testing.assert_array_equal(got.cpu().numpy(), want_o)
-        # and the sub-pixel shift it implies is the true one to the grid resolution
-        shift = coarse + (got.cpu().numpy() - 75.0) / 100
-        assert np.abs(shift - true).max() < 0.02
+        peak_o = np.stack(np.unravel_index(np.abs(ref).reshape(nscan, -1).argmax(1), (150, 150)), axis=1)
+        want = coarse + (peak_o - 75.0) / 100
+        dip = torch.as_tensor(ip, device="cuda")
+        dmax = torch.as_tensor(maxima, device="cuda")
+        packed = (0xffffffff - (dmax[:, 0] * ndet + dmax[:, 1])).contiguous()
+        got = P._zoom_shifts_native(slv, dip, packed, 100)
+        assert got is not None, "native zoom kernels declined a case they should cover"
+        np.testing.assert_array_equal(got.cpu().numpy(), want)
+        # the torch GEMM fallback (torch divides by a scalar through its reciprocal: 1 ulp) and
+        # the public wrapper agree as well
+        np.testing.assert_allclose(P._finish_registration(dip, dmax, 100).cpu().numpy(), want, rtol=0, atol=1e-13)
+        np.testing.assert_array_equal(P._finish_registration(dip, dmax, 100, op=slv).cpu().numpy(), want)
+        assert np.abs(got.cpu().numpy() - true).max() < 0.02
