@@ -38,6 +38,6 @@ def run(name, R, step, nprb, ndet, nmodes, cg_iters):
     print(json.dumps(out), flush=True)
     slv.free(); del data; torch.cuda.empty_cache()
 which = sys.argv[1] if len(sys.argv) > 1 else "all"
-if which in ("all", "pad"): run("configs[1] with nprb=128<ndet=256", 64, 8, 128, 256, 1, 6)
+if which in ("all", "pad"): run("configs[1] with nprb=128<ndet=256", 64, 8, 128, 256, 1, 20)
 if which in ("all", "c2"): run("configs[1]", 64, 8, 256, 256, 1, 6)
-if which in ("all", "c3"): run("configs[2]: 512^2, 4 modes", 64, 8, 512, 512, 4, 3)
+if which in ("all", "c3"): run("configs[2]: 512^2, 4 modes", 64, 8, 512, 512, 4, 10)
