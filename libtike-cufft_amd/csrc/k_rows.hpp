@@ -197,6 +197,7 @@ __global__ __launch_bounds__(256) void k_rows_fused(const RowFusedArgs a) {
     constexpr int NACC = EP == EP_STATS ? 2 : (EP == EP_LINESEARCH ? kMaxCand + 1 : 1);
     __shared__ c32 lds[P::NSTEP > 1 ? B * L::FS : 1];
     __shared__ double red[4 * NACC];
+    __shared__ c32 stash[EP == EP_CROSS ? E * 256 : 1];
 
     const int tid = threadIdx.x;
     const int f = tid / T, j0 = tid % T;
@@ -242,14 +243,17 @@ __global__ __launch_bounds__(256) void k_rows_fused(const RowFusedArgs a) {
     for (long long batch = blockIdx.x; batch < nb; batch += gridDim.x) {
         const long long r = batch * B + f;
         const bool ok = r < a.nrows;
-        const size_t rowoff = (size_t)r * N;
+        // addresses = wave-uniform batch base (scalar registers) + 32-bit per-thread offset: the
+        // loads / stores take the saddr form and no 64-bit address lives in a VGPR
+        const size_t boff = (size_t)batch * B * N;
+        const unsigned fN = (unsigned)(f * N);
         c32 v[E], g1[E];
-        fft.template load<0>(v, j0, [&](int i) { return (ok && i >= a.xa && i < a.xb) ? __builtin_nontemporal_load(a.s1 + rowoff + i) : zero; });
+        fft.template load<0>(v, j0, [&](int i) { return (ok && i >= a.xa && i < a.xb) ? __builtin_nontemporal_load(a.s1 + boff + (fN + (unsigned)i)) : zero; });
         fwd_row(v, g1);
         float d[E];
         auto load_data = [&]() {
 #pragma unroll
-            for (int m = 0; m < E; ++m) d[m] = ok ? __builtin_nontemporal_load(a.data + rowoff + j0 + m * T) : 0.0f;
+            for (int m = 0; m < E; ++m) d[m] = ok ? __builtin_nontemporal_load(a.data + boff + (fN + (unsigned)(j0 + m * T))) : 0.0f;
         };
         if (EP == EP_STATS || EP == EP_PROJECT) load_data();
         if (EP == EP_CROSS) {
@@ -257,13 +261,19 @@ __global__ __launch_bounds__(256) void k_rows_fused(const RowFusedArgs a) {
             // = u1 + gamma G dpsi (ones probe); image product u1 conj(u2) is kept for the zoomed
             // DFT and its inverse row DFT goes back into the slot (column pass + arg-max follow).
             c32 g2[E], rr[E];
-            fft.template load<0>(v, j0, [&](int i) { return (ok && i >= a.xa && i < a.xb) ? __builtin_nontemporal_load(a.s2 + rowoff + i) : zero; });
+            // u1 waits in LDS (private slots, no barrier) while the second row is transformed: the
+            // kernel then fits 256 VGPRs and two waves per SIMD instead of one
+#pragma unroll
+            for (int m = 0; m < E; ++m) stash[m * 256 + tid] = g1[m];
+            fft.template load<0>(v, j0, [&](int i) { return (ok && i >= a.xa && i < a.xb) ? __builtin_nontemporal_load(a.s2 + boff + (fN + (unsigned)i)) : zero; });
             fwd_row(v, g2);
+#pragma unroll
+            for (int m = 0; m < E; ++m) g1[m] = stash[m * 256 + tid];
 #pragma unroll
             for (int m = 0; m < E; ++m) {
                 const c32 u2 = g1[m] + g2[m] * a.gamma0;
                 rr[m] = cmulc(g1[m], u2);
-                if (ok) __builtin_nontemporal_store(rr[m], a.ip + rowoff + j0 + m * T);
+                if (ok) __builtin_nontemporal_store(rr[m], a.ip + boff + (fN + (unsigned)(j0 + m * T)));
             }
             F::from_natural(rr, v);
             fft.template compute_rev<0>(v);
@@ -281,7 +291,7 @@ __global__ __launch_bounds__(256) void k_rows_fused(const RowFusedArgs a) {
                 fft.template compute_rev<LAST>(v);
             }
             fft.template store<LAST>(v, j0, [&](int i, c32 val) {
-                if (ok) __builtin_nontemporal_store(val, a.out + rowoff + i);
+                if (ok) __builtin_nontemporal_store(val, a.out + boff + (fN + (unsigned)i));
             });
             if (P::NSTEP > 1) __syncthreads();
             continue;
@@ -299,18 +309,18 @@ __global__ __launch_bounds__(256) void k_rows_fused(const RowFusedArgs a) {
 #pragma unroll
                 for (int m = 0; m < E; ++m) {
                     const float I = g1[m].x * g1[m].x + g1[m].y * g1[m].y;
-                    float* o = a.acc1 + rowoff + j0 + m * T;
+                    float* o = a.acc1 + boff + (fN + (unsigned)(j0 + m * T));
                     *o = a.first ? I : *o + I;
                 }
             }
         } else if (EP == EP_ACCUM_P) {
             c32 g2[E];
-            fft.template load<0>(v, j0, [&](int i) { return (ok && i >= a.xa && i < a.xb) ? __builtin_nontemporal_load(a.s2 + rowoff + i) : zero; });
+            fft.template load<0>(v, j0, [&](int i) { return (ok && i >= a.xa && i < a.xb) ? __builtin_nontemporal_load(a.s2 + boff + (fN + (unsigned)i)) : zero; });
             fwd_row(v, g2);
             if (ok) {
 #pragma unroll
                 for (int m = 0; m < E; ++m) {
-                    const size_t o = rowoff + j0 + m * T;
+                    const size_t o = boff + (fN + (unsigned)(j0 + m * T));
                     const c32 t1 = g1[m] * s;
                     const float p1 = t1.x * t1.x + t1.y * t1.y;
                     const float p2 = g2[m].x * g2[m].x + g2[m].y * g2[m].y;
@@ -327,7 +337,7 @@ __global__ __launch_bounds__(256) void k_rows_fused(const RowFusedArgs a) {
             for (int m = 0; m < E; ++m) {
                 // single mode: S comes from the unscaled probe -> I' = |g|^2 s^2, fpsi = (g s)(1/s');
                 // multi mode: S comes from the rescaled probe and I is the summed intensity array
-                const float I = a.inten ? (ok ? a.inten[rowoff + j0 + m * T] : 0.0f) * s2
+                const float I = a.inten ? (ok ? a.inten[boff + (fN + (unsigned)(j0 + m * T))] : 0.0f) * s2
                                         : (g1[m].x * g1[m].x + g1[m].y * g1[m].y) * s2;
                 const c32 fp = a.inten ? g1[m] * sinv : (g1[m] * s) * sinv;
                 const float sd = fsqrt(d[m]), sI = fsqrt(I);
@@ -352,12 +362,12 @@ __global__ __launch_bounds__(256) void k_rows_fused(const RowFusedArgs a) {
                 fft.template compute_rev<LAST>(v);
             }
             fft.template store<LAST>(v, j0, [&](int i, c32 val) {
-                if (ok) __builtin_nontemporal_store(val, a.out + rowoff + i);
+                if (ok) __builtin_nontemporal_store(val, a.out + boff + (fN + (unsigned)i));
             });
             if (P::NSTEP > 1) __syncthreads();
         } else {   // EP_LINESEARCH
             c32 g2[E];
-            fft.template load<0>(v, j0, [&](int i) { return (ok && i >= a.xa && i < a.xb) ? __builtin_nontemporal_load(a.s2 + rowoff + i) : zero; });
+            fft.template load<0>(v, j0, [&](int i) { return (ok && i >= a.xa && i < a.xb) ? __builtin_nontemporal_load(a.s2 + boff + (fN + (unsigned)i)) : zero; });
             fwd_row(v, g2);
             load_data();   // after the second transform: keeps 16 registers free during it
             // two detector pixels per step in packed float32 (v_pk_fma_f32 / v_pk_add_f32), four
