@@ -683,11 +683,14 @@ class CGPtychoSolver(PtychoHIP):
         return {"psi": psi, "probe": probe}
 
     # -- fused multi-mode gaussian loop ----------------------------------------------------
-    def _array_line_search(self, p1, p2, p3, data, costs):
-        """All trials of ``line_search_sqr`` (ptycho.py:253-281) on stored p1, p2, p3:
-        16 step lengths per pass (the kernel takes up to 32); ``costs`` has 33 entries."""
+    def _array_line_search(self, p1, p2, p3, data, costs, which="psi"):
+        """All trials of ``line_search_sqr`` (ptycho.py:253-281) on stored p1, p2, p3, up to 32
+        step lengths per pass; ``costs`` has 33 entries.  The number priced per pass follows the
+        last accepted index of the same search (``which``), as in ``_fused_line_search``."""
+        hints = self.__dict__.setdefault("_ls_hint", {})
+        nc = min(32, max(2, hints.get(which, 14) + 2))
         gamma0 = 1.0
-        nc = 16
+        tried = 0
         while True:
             costs.zero_()
             nat.check(nat.cg_array_costs(self._h, _ptr(p1), _ptr(p2), _ptr(p3), _ptr(data), gamma0, nc,
@@ -697,12 +700,16 @@ class CGPtychoSolver(PtychoHIP):
             step = gamma0
             for j in range(nc):
                 if not (c[j] > c[nc]):
+                    hints[which] = tried + j
                     return step
                 if step < 1e-32:
                     warnings.warn("Line search failed for conjugate gradient.")
+                    hints[which] = 14
                     return 0
                 step *= 0.5
             gamma0 = step
+            tried += nc
+            nc = 32
 
     def _run_fused_multi(self, data, psi, scan, probe, piter, recover_prb):
         """``CGPtychoSolver.run`` (ptycho.py:283-488), gaussian model, any number of
@@ -794,7 +801,7 @@ class CGPtychoSolver(PtychoHIP):
                     self._cg_fwd_cols(0, psi, scan, mode(probe, m))
                     self._cg_fwd_cols(1, psi, scan, mode(dprb, m))
                     nat.check(nat.cg_accum_terms(self._h, 0, 1, _ptr(p1), _ptr(p2), _ptr(p3), 1, None, _stream()))
-                    gammaprb = 0.5 * self._array_line_search(inten, p2, p3, data, costs)
+                    gammaprb = 0.5 * self._array_line_search(inten, p2, p3, data, costs, which="prb%d" % m)
                     probe[:, m] = probe[:, m] + gammaprb * dprb[:, m]
 
             if i % self.log_every == 0:
