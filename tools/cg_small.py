@@ -1,0 +1,17 @@
+"""CG iteration rate at 512 positions (one GPU's share of config 2 under 8-way strong scaling)."""
+import sys, time; sys.path.insert(0,'.'); sys.path.insert(0,'libtike-cufft_amd')
+import numpy as np, torch
+import libtike.hipfft as pt
+from libtike.hipfft import synthetic as syn
+for (R1, R2) in ((64, 64), (16, 32), (8, 8)):
+    p = syn.make_problem(R1, R2, 8, 256, 256, seed=1234)
+    D=lambda x: torch.as_tensor(x,device='cuda')
+    slv = pt.CGPtychoSolver(p['nscan'],256,256,1,p['nz'],p['n']); slv.verbose=False
+    psi,scan,prb = D(p['psi']),D(p['scan']),D(p['probe'])
+    data = (torch.abs(slv.fwd(psi,scan,prb))**2).contiguous()
+    slv.run(data, torch.ones_like(psi), scan.clone(), prb[:,None].clone(), piter=3); torch.cuda.synchronize()
+    t=time.perf_counter()
+    slv.run(data, torch.ones_like(psi), scan.clone(), prb[:,None].clone(), piter=50); torch.cuda.synchronize()
+    dt=(time.perf_counter()-t)/50
+    print(p['nscan'], "positions: %.2f ms/iter, %.1f it/s" % (dt*1e3, 1/dt))
+    slv.free()
