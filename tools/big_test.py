@@ -29,3 +29,18 @@ def T(f,n=3):
 del Ax
 tf = T(lambda: slv.fwd(psi,scan,prb)); ta = T(lambda: slv.adj(y,scan,prb))
 print("fwd ms", tf, "adj ms", ta, "patterns/s pair", R1*R2/((tf+ta)*1e-3))
+# CG on the same shard (data = |fwd|^2, 10 iterations from a flat object, position correction on)
+del y, Aty, Bty
+torch.cuda.empty_cache()
+cg = pt.CGPtychoSolver(R1*R2,256,256,1,nz,n); cg.verbose = False
+data = torch.empty((1, R1*R2, 256, 256), dtype=torch.float32, device='cuda')
+for i in range(0, R1*R2, 4096):
+    g = slv.fwd(psi, scan, prb) if i == 0 else g
+    data[:, i:i+4096] = torch.abs(g[:, i:i+4096])**2
+del g
+slv.free()
+cg.run(data, torch.ones_like(psi), scan.clone(), prb[None].clone().reshape(1,1,256,256), piter=2); torch.cuda.synchronize()
+t=time.perf_counter()
+out = cg.run(data, torch.ones_like(psi), scan.clone(), prb[None].clone().reshape(1,1,256,256), piter=10); torch.cuda.synchronize()
+dt=(time.perf_counter()-t)/10
+print("CG 32768 positions: %.1f ms/iter, %.2f it/s, psi finite %s" % (dt*1e3, 1/dt, bool(torch.isfinite(out['psi']).all())))
