@@ -162,8 +162,13 @@ __global__ __launch_bounds__(ColCfg<N>::NT) void k_cols_adjwin(const ColArgs a, 
 #pragma unroll
             for (int m = 0; m < E; ++m) {
                 const c32 w = pr[m];
-                lds[at(j0 + m * T)] = c32{w.x * nat[m].x + w.y * nat[m].y, w.x * nat[m].y - w.y * nat[m].x};
+                nat[m] = c32{w.x * nat[m].x + w.y * nat[m].y, w.x * nat[m].y - w.y * nat[m].x};
             }
+            // split kernel: no exchange went through the tile, so the "previous combine is done"
+            // barrier sits here, after this position's transform, instead of at the end of the loop
+            if (SPLIT) __syncthreads();
+#pragma unroll
+            for (int m = 0; m < E; ++m) lds[at(j0 + m * T)] = nat[m];
         }
         // prefetch the next tile while the combine runs
         if (nx.have && nx.q.valid) {
@@ -214,7 +219,7 @@ __global__ __launch_bounds__(ColCfg<N>::NT) void k_cols_adjwin(const ColArgs a, 
                 slot = slot + 1 == H ? 0 : slot + 1;
             }
         }
-        __syncthreads();   // combine done: the tile may be overwritten by the next position
+        if (!SPLIT) __syncthreads();   // combine done: the tile may be overwritten by the next position
         st = nx;
     }
     __syncthreads();
