@@ -54,6 +54,29 @@ def test_argument_validation_needs_no_gpu(nat):
     assert nat.fwd(None, None, None, None, None, None) == 1            # null handle
     assert nat.get(None, 0) == -1
     assert nat.destroy(None) == 0
+    # every CG-stage entry point rejects a null handle before touching the device
+    assert nat.cg_zoom(None, None, None, None, None, 9, 150, 100.0, None, None) == 1
+    assert nat.cg_cross(None, 0, 1, 0.5, None, None) == 1
+    assert nat.cg_argmax(None, 1, None, None) == 1
+    assert nat.cg_linesearch(None, 0, 1, None, None, 1.0, 16, None, None) == 1
+    assert b"null handle" in nat.last_error()
+
+
+def test_zoom_window_kernel_is_low_rank():
+    """Host side of ``ptycho_cg_zoom``: the real factors of the centred window kernel
+    reproduce ``exp(i theta_k jc)`` to float64 noise with 16 terms for every supported size."""
+    import numpy as np
+    from libtike.hipfft import ptycho as P
+    for npts in (16, 64, 256, 1024):
+        vt, lz, nc = P._zoom_real_factors(npts, 150, 100, "cpu")
+        vt, lz = vt.numpy(), lz.numpy()
+        assert vt.shape == (npts, 16) and lz.shape == (150, 16) and 8 <= nc <= 9
+        th = 2 * np.pi * np.fft.fftfreq(npts, 100)
+        jc = np.arange(150) - 74.5
+        want = np.exp(1j * jc[:, None] * th[None, :])
+        got = lz[:, :nc] @ vt[:, :nc].T + 1j * (lz[:, nc:] @ vt[:, nc:].T)
+        assert np.abs(got - want).max() < 2e-13
+    assert P._zoom_real_factors(256, 150, 1, "cpu") is None      # a window that is not low rank
 
 
 def test_fft_core_on_host():
