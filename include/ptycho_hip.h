@@ -26,7 +26,7 @@
  *   g    farplane complex64 [ptheta][nscan][ndet][ndet]   (DC at [0][0])
  *   prb  probe    complex64 [ptheta][nprb][nprb]
  *   scan          float32   [ptheta][nscan][2]  ([..][0] = row/y, [..][1] = column/x)
- * ndet must be a power of two in [16, 1024]; nprb <= ndet.
+ * ndet must be a power of two in [16, 2048]; nprb <= ndet.
  */
 #ifndef PTYCHO_HIP_H
 #define PTYCHO_HIP_H

@@ -103,6 +103,7 @@ template <> struct Plan<128> : PlanT<128, 16, 8> {};
 template <> struct Plan<256> : PlanT<256, 16, 16> {};
 template <> struct Plan<512> : PlanT<512, 8, 8, 8> {};
 template <> struct Plan<1024> : PlanT<1024, 16, 16, 4> {};
+template <> struct Plan<2048> : PlanT<2048, 16, 16, 8> {};
 
 // Per-thread FFT state: E points, the inter-step twiddles (loop invariant, so
 // they stay in registers across the whole batch loop of a kernel).

@@ -105,12 +105,14 @@ int main() {
     worst = std::fmax(worst, check_plan<256, -1>());
     worst = std::fmax(worst, check_plan<512, -1>());
     worst = std::fmax(worst, check_plan<1024, -1>());
+    worst = std::fmax(worst, check_plan<2048, -1>());
     worst = std::fmax(worst, check_plan<32, 1>());
     worst = std::fmax(worst, check_plan<64, 1>());
     worst = std::fmax(worst, check_plan<128, 1>());
     worst = std::fmax(worst, check_plan<256, 1>());
     worst = std::fmax(worst, check_plan<512, 1>());
     worst = std::fmax(worst, check_plan<1024, 1>());
+    worst = std::fmax(worst, check_plan<2048, 1>());
     std::printf("worst=%.3e %s\n", worst, worst < 5e-6 ? "OK" : "FAIL");
     return worst < 5e-6 ? 0 : 1;
 }

@@ -13,7 +13,8 @@ template <int N>
 struct ColCfg {
     static constexpr int T = Plan<N>::T;
     static constexpr int C0 = (256 / T) > 16 ? (256 / T) : 16;
-    static constexpr int C = C0 > N ? N : C0;   // detector columns per strip
+    static constexpr int C1 = C0 > N ? N : C0;
+    static constexpr int C = T * C1 > 1024 ? 1024 / T : C1;   // detector columns per strip (<= 1024 threads)
     static constexpr int NT = T * C;            // threads per workgroup
 };
 

@@ -625,7 +625,8 @@ int do_cg_rows(ptycho_handle h, RowFusedArgs a, hipStream_t st) {
         case 256: { constexpr int NN = 256; return CALL; }       \
         case 512: { constexpr int NN = 512; return CALL; }       \
         case 1024: { constexpr int NN = 1024; return CALL; }     \
-        default: return fail(PTYCHO_ERR_ARG, "ndet must be a power of two in [16, 1024]"); \
+        case 2048: { constexpr int NN = 2048; return CALL; }     \
+        default: return fail(PTYCHO_ERR_ARG, "ndet must be a power of two in [16, 2048]"); \
     }
 
 int check_handle(ptycho_handle h) {
@@ -691,8 +692,8 @@ int ptycho_create(ptycho_handle* out, size_t ptheta, size_t nz, size_t n, size_t
     *out = nullptr;
     if (ptheta == 0 || nz == 0 || n == 0 || nscan == 0 || ndet == 0 || nprb == 0)
         return fail(PTYCHO_ERR_ARG, "all sizes must be positive");
-    if (ndet < 16 || ndet > 1024 || (ndet & (ndet - 1)) != 0)
-        return fail(PTYCHO_ERR_ARG, "ndet must be a power of two in [16, 1024]");
+    if (ndet < 16 || ndet > 2048 || (ndet & (ndet - 1)) != 0)
+        return fail(PTYCHO_ERR_ARG, "ndet must be a power of two in [16, 2048]");
     if (nprb > ndet) return fail(PTYCHO_ERR_ARG, "nprb must be <= ndet");
     if (ptheta * nscan > (size_t)0x7fffffff / 2 || ptheta > (1u << 19) || nz > 65536 * 4 || n > 65536 * 4)
         return fail(PTYCHO_ERR_ARG, "problem too large for 32-bit position indices");

@@ -81,7 +81,7 @@ class PtychoHIP:
     ----------
     nscan : int   scan positions per angular view
     nprb : int    probe is ``nprb x nprb``
-    ndet : int    detector is ``ndet x ndet`` (power of two, 16..1024)
+    ndet : int    detector is ``ndet x ndet`` (power of two, 16..2048)
     ptheta : int  angular views processed per call
     n, nz : int   object width, height
     """

@@ -72,6 +72,8 @@ CASES = [
     (512, 512, 2, 2, 17, 1),
     (512, 300, 2, 2, 17, 1),
     (1024, 1024, 1, 2, 17, 1),
+    (2048, 2048, 1, 2, 19, 1),
+    (2048, 1500, 1, 2, 19, 1),
 ]
 
 
@@ -208,7 +210,7 @@ def test_experimental_paths_give_the_same_results(pt):
 
 def test_fft2_matches_numpy(pt):
     rng = np.random.default_rng(0)
-    for ndet in (16, 32, 64, 128, 256, 512, 1024):
+    for ndet in (16, 32, 64, 128, 256, 512, 1024, 2048):
         nb = 3
         x = (rng.standard_normal((nb, ndet, ndet)) + 1j * rng.standard_normal((nb, ndet, ndet))).astype(np.complex64)
         with pt.PtychoCuFFT(1, ndet, ndet, 1, ndet + 2, ndet + 2) as slv:

@@ -80,7 +80,7 @@ def test_zoom_window_kernel_is_low_rank():
 
 
 def test_fft_core_on_host():
-    """Stockham index math of csrc/fft_core.hpp for every plan (16..1024, both
+    """Stockham index math of csrc/fft_core.hpp for every plan (16..2048, both
     directions) emulated thread by thread on the host against a naive DFT."""
     exe = "/tmp/pty_host_check"
     subprocess.run(["/opt/rocm/lib/llvm/bin/clang++", "-std=c++17", "-O2",
