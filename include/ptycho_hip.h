@@ -75,7 +75,8 @@ int ptycho_fft2(ptycho_handle h, void* dst, const void* src, size_t nbatch,
 /* ---- fused CG-stage entry points ("plus fused CG-stage entry points") ----
  * The elementwise stages of CGPtychoSolver.run (src/libtike/cufft/ptycho.py:325-393) are
  * fused into the row pass of the DFT so that farplanes are never materialised.  The
- * handle owns two work buffers ("slots" 0/1, one farplane each, allocated on first use)
+ * handle owns work buffers ("slots" 0..15, one farplane each, allocated on first use; the
+ * single-mode loop uses 0 and 1, the multi-mode loop one pair (2k, 2k+1) per probe mode)
  * that hold column-pass intermediates between calls.  sums/cost/costs and ab are DEVICE
  * pointers to float64 (ab = {a, b} of ptycho.py:342-343; NULL means scale 1); the
  * kernels ADD into sums/cost/costs, the caller zeroes them.
@@ -99,23 +100,24 @@ int ptycho_cg_linesearch(ptycho_handle h, int slot1, int slot2, const void* data
                          void* stream);
 
 /* Multi-mode variants (ptycho.py:330-333,349-356,386-391,425-434 loop over probe modes):
- * the summed intensity and the line-search terms p1,p2,p3 are float32 arrays
- * [ptheta][nscan][ndet][ndet] owned by the caller.
+ * the summed intensity is a float32 array [ptheta][nscan][ndet][ndet] owned by the caller;
+ * each mode k has its own pair of work slots (2k, 2k+1).
  *   ptycho_cg_accum_intensity  inten (first ? = : +=) |g|^2 of the slot
  *   ptycho_cg_array_stats      sums += { sum sqrt(inten d), sum inten }
- *   ptycho_cg_project_multi    as ptycho_cg_project with I = inten * (a/b)^2 (slot from the rescaled probe)
- *   ptycho_cg_accum_terms      p1,p2,p3 (first ? = : +=) |t1|^2, |t2|^2, 2 Re(t1 conj t2), t1 = (a/b) g1 if ab
- *   ptycho_cg_array_costs      as ptycho_cg_linesearch on stored p1,p2,p3, up to 32 step lengths per pass */
+ *   ptycho_cg_project_multi    as ptycho_cg_project with I = inten * (a/b)^2; slot_unscaled = 0: the slot was
+ *                              made with the rescaled probe, 1: with the probe before its rescale
+ *   ptycho_cg_linesearch_modes as ptycho_cg_linesearch with p1,p2,p3 summed in registers over the mode
+ *                              pairs (slot 2k, slot 2k+1), mode0 <= k < mode0 + nmodes <= 8 (no arrays); p1 = inten if given
+ */
 int ptycho_cg_accum_intensity(ptycho_handle h, int slot, void* inten, int first, void* stream);
 int ptycho_cg_array_stats(ptycho_handle h, const void* inten, const void* data, double* sums,
                           void* stream);
 int ptycho_cg_project_multi(ptycho_handle h, int src_slot, int dst_slot, const void* data,
-                            const void* inten, const double* ab, double* cost, void* stream);
-int ptycho_cg_accum_terms(ptycho_handle h, int slot1, int slot2, void* p1, void* p2, void* p3,
-                          int first, const double* ab, void* stream);
-int ptycho_cg_array_costs(ptycho_handle h, const void* p1, const void* p2, const void* p3,
-                          const void* data, double gamma0, int ncand, double* costs,
-                          void* stream);
+                            const void* inten, const double* ab, int slot_unscaled, double* cost,
+                            void* stream);
+int ptycho_cg_linesearch_modes(ptycho_handle h, int mode0, int nmodes, const void* data, const void* inten,
+                               const double* ab, double gamma0, int ncand, double* costs,
+                               void* stream);
 
 /* Position correction (ptycho.py:398-403 + 198-207), fused: with the column passes of
  * fwd(psi, 1) in slot1 and fwd(dpsi, 1) in slot2,

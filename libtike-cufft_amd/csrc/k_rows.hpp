@@ -163,7 +163,8 @@ __global__ __launch_bounds__(256) void k_rows_split(const RowArgs a) {
 __device__ __forceinline__ float fsqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
 __device__ __forceinline__ float frcp(float x) { return __builtin_amdgcn_rcpf(x); }
 
-enum RowEp { EP_STATS = 1, EP_PROJECT = 2, EP_LINESEARCH = 3, EP_ACCUM_I = 4, EP_ACCUM_P = 5, EP_CROSS = 6 };
+enum RowEp { EP_STATS = 1, EP_PROJECT = 2, EP_LINESEARCH = 3, EP_ACCUM_I = 4, EP_CROSS = 6, EP_LINESEARCH_M = 7 };
+constexpr int kMaxModes = 8;   // EP_LINESEARCH_M: slot pairs (2k, 2k+1), k < nmodes
 constexpr int kMaxCand = 16;
 
 struct RowFusedArgs {
@@ -180,10 +181,12 @@ struct RowFusedArgs {
     int xa, xb;          // columns outside [xa, xb) of the inputs are zero (never written)
     // multi-mode variants (arrays are float32 [positions][ndet][ndet])
     const float* inten;  // EP_PROJECT: summed intensity of all modes (nullptr: single mode, |g|^2)
-    float* acc1;         // EP_ACCUM_I: intensity;  EP_ACCUM_P: p1
-    float* acc2;         // EP_ACCUM_P: p2
-    float* acc3;         // EP_ACCUM_P: p3
-    int first;           // 1: overwrite the arrays, 0: add to them
+    float* acc1;         // EP_ACCUM_I: intensity
+    int first;           // 1: overwrite the arrays, 0: add to them; EP_PROJECT with inten: 1 = the slot was
+                         // made with the probe BEFORE its rescale (fp = (g s)(1/s) as in the single-mode path)
+    // EP_LINESEARCH_M: t1_k = s * DFT_x(sm[2k]), t2_k = DFT_x(sm[2k+1]); p1 = inten if given, else sum_k |t1_k|^2
+    const c32* sm[2 * kMaxModes];
+    int nmodes;
     c32* ip;             // EP_CROSS: image product u1 * conj(u2), [positions][ndet][ndet]
 };
 
@@ -194,10 +197,11 @@ __global__ __launch_bounds__(256) void k_rows_fused(const RowFusedArgs a) {
     using L = RowLds<N>;
     constexpr int E = P::E, T = P::T, B = 256 / T;
     constexpr int LAST = P::NSTEP - 1;
-    constexpr int NACC = EP == EP_STATS ? 2 : (EP == EP_LINESEARCH ? kMaxCand + 1 : 1);
+    constexpr bool LS = EP == EP_LINESEARCH || EP == EP_LINESEARCH_M;
+    constexpr int NACC = EP == EP_STATS ? 2 : (LS ? kMaxCand + 1 : 1);
     __shared__ c32 lds[P::NSTEP > 1 ? B * L::FS : 1];
     __shared__ double red[4 * NACC];
-    __shared__ c32 stash[EP == EP_CROSS ? E * 256 : 1];
+    __shared__ c32 stash[(EP == EP_CROSS || EP == EP_LINESEARCH_M) ? E * 256 : 1];
 
     const int tid = threadIdx.x;
     const int f = tid / T, j0 = tid % T;
@@ -205,11 +209,11 @@ __global__ __launch_bounds__(256) void k_rows_fused(const RowFusedArgs a) {
     fft.init(j0, a.table);
     const c32 zero = c32{0.0f, 0.0f};
     float acc[NACC];
-    c32 acc2[EP == EP_LINESEARCH ? NACC : 1];   // line search: even / odd pixel partial sums
+    c32 acc2[LS ? NACC : 1];   // line search: even / odd pixel partial sums
 #pragma unroll
     for (int i = 0; i < NACC; ++i) acc[i] = 0.0f;
 #pragma unroll
-    for (int i = 0; i < (EP == EP_LINESEARCH ? NACC : 1); ++i) acc2[i] = c32{0.0f, 0.0f};
+    for (int i = 0; i < (LS ? NACC : 1); ++i) acc2[i] = c32{0.0f, 0.0f};
 
     // scale factors of ptycho.py:344-351 in float32, as the reference computes them
     float s = 1.0f, sinv = 1.0f;
@@ -248,7 +252,8 @@ __global__ __launch_bounds__(256) void k_rows_fused(const RowFusedArgs a) {
         const size_t boff = (size_t)batch * B * N;
         const unsigned fN = (unsigned)(f * N);
         c32 v[E], g1[E];
-        fft.template load<0>(v, j0, [&](int i) { return (ok && i >= a.xa && i < a.xb) ? __builtin_nontemporal_load(a.s1 + boff + (fN + (unsigned)i)) : zero; });
+        const c32* __restrict__ first_src = EP == EP_LINESEARCH_M ? a.sm[0] : a.s1;
+        fft.template load<0>(v, j0, [&](int i) { return (ok && i >= a.xa && i < a.xb) ? __builtin_nontemporal_load(first_src + boff + (fN + (unsigned)i)) : zero; });
         fwd_row(v, g1);
         float d[E];
         auto load_data = [&]() {
@@ -313,23 +318,6 @@ __global__ __launch_bounds__(256) void k_rows_fused(const RowFusedArgs a) {
                     *o = a.first ? I : *o + I;
                 }
             }
-        } else if (EP == EP_ACCUM_P) {
-            c32 g2[E];
-            fft.template load<0>(v, j0, [&](int i) { return (ok && i >= a.xa && i < a.xb) ? __builtin_nontemporal_load(a.s2 + boff + (fN + (unsigned)i)) : zero; });
-            fwd_row(v, g2);
-            if (ok) {
-#pragma unroll
-                for (int m = 0; m < E; ++m) {
-                    const size_t o = boff + (fN + (unsigned)(j0 + m * T));
-                    const c32 t1 = g1[m] * s;
-                    const float p1 = t1.x * t1.x + t1.y * t1.y;
-                    const float p2 = g2[m].x * g2[m].x + g2[m].y * g2[m].y;
-                    const float p3 = 2.0f * (t1.x * g2[m].x + t1.y * g2[m].y);
-                    a.acc1[o] = a.first ? p1 : a.acc1[o] + p1;
-                    a.acc2[o] = a.first ? p2 : a.acc2[o] + p2;
-                    a.acc3[o] = a.first ? p3 : a.acc3[o] + p3;
-                }
-            }
         } else if (EP == EP_PROJECT) {
             const float s2 = s * s;
             c32 rr[E];
@@ -339,7 +327,7 @@ __global__ __launch_bounds__(256) void k_rows_fused(const RowFusedArgs a) {
                 // multi mode: S comes from the rescaled probe and I is the summed intensity array
                 const float I = a.inten ? (ok ? a.inten[boff + (fN + (unsigned)(j0 + m * T))] : 0.0f) * s2
                                         : (g1[m].x * g1[m].x + g1[m].y * g1[m].y) * s2;
-                const c32 fp = a.inten ? g1[m] * sinv : (g1[m] * s) * sinv;
+                const c32 fp = (a.inten && !a.first) ? g1[m] * sinv : (g1[m] * s) * sinv;
                 const float sd = fsqrt(d[m]), sI = fsqrt(I);
                 rr[m] = fp - (fp * sd) * frcp(sI + 1e-32f);
                 const float df = sI - sd;
@@ -365,6 +353,57 @@ __global__ __launch_bounds__(256) void k_rows_fused(const RowFusedArgs a) {
                 if (ok) __builtin_nontemporal_store(val, a.out + boff + (fN + (unsigned)i));
             });
             if (P::NSTEP > 1) __syncthreads();
+        } else if (EP == EP_LINESEARCH_M) {
+            // multi-mode line search (ptycho.py:383-393 with the sums over k of :386-391): the terms
+            // p1, p2, p3 are accumulated over the modes in registers, never stored
+            float p1[E], p2[E], p3[E];
+#pragma unroll
+            for (int m = 0; m < E; ++m) { p1[m] = 0.0f; p2[m] = 0.0f; p3[m] = 0.0f; }
+            for (int k = 0; k < a.nmodes; ++k) {
+                if (k > 0) {
+                    const c32* __restrict__ src1 = a.sm[2 * k];
+                    fft.template load<0>(v, j0, [&](int i) { return (ok && i >= a.xa && i < a.xb) ? __builtin_nontemporal_load(src1 + boff + (fN + (unsigned)i)) : zero; });
+                    fwd_row(v, g1);
+                }
+#pragma unroll
+                for (int m = 0; m < E; ++m) stash[m * 256 + tid] = g1[m];   // t1 waits in LDS (private slots)
+                const c32* __restrict__ src2 = a.sm[2 * k + 1];
+                c32 g2[E];
+                fft.template load<0>(v, j0, [&](int i) { return (ok && i >= a.xa && i < a.xb) ? __builtin_nontemporal_load(src2 + boff + (fN + (unsigned)i)) : zero; });
+                fwd_row(v, g2);
+#pragma unroll
+                for (int m = 0; m < E; ++m) {
+                    const c32 t1 = stash[m * 256 + tid] * s;
+                    p1[m] += t1.x * t1.x + t1.y * t1.y;
+                    p2[m] += g2[m].x * g2[m].x + g2[m].y * g2[m].y;
+                    p3[m] += 2.0f * (t1.x * g2[m].x + t1.y * g2[m].y);
+                }
+            }
+            load_data();
+            if (a.inten) {
+#pragma unroll
+                for (int m = 0; m < E; ++m) p1[m] = ok ? a.inten[boff + (fN + (unsigned)(j0 + m * T))] : 0.0f;
+            }
+#pragma unroll
+            for (int m = 0; m < E; m += 2) {
+                const c32 q1 = c32{p1[m], p1[m + 1]}, q2 = c32{p2[m], p2[m + 1]}, q3 = c32{p3[m], p3[m + 1]};
+                const c32 sd = c32{fsqrt(d[m]), fsqrt(d[m + 1])};
+                c32 df = c32{fsqrt(fabsf(q1.x)), fsqrt(fabsf(q1.y))} - sd;
+                acc2[kMaxCand] += df * df;
+                float gam = a.gamma0;
+#pragma unroll
+                for (int j0c = 0; j0c < kMaxCand; j0c += 4) {
+                    if (j0c < a.ncand) {
+#pragma unroll
+                        for (int j = j0c; j < j0c + 4; ++j) {
+                            const c32 xx = q1 + q2 * (gam * gam) + q3 * gam;
+                            df = c32{fsqrt(fabsf(xx.x)), fsqrt(fabsf(xx.y))} - sd;
+                            acc2[j] += df * df;
+                            gam *= 0.5f;
+                        }
+                    }
+                }
+            }
         } else {   // EP_LINESEARCH
             c32 g2[E];
             fft.template load<0>(v, j0, [&](int i) { return (ok && i >= a.xa && i < a.xb) ? __builtin_nontemporal_load(a.s2 + boff + (fN + (unsigned)i)) : zero; });
@@ -398,11 +437,11 @@ __global__ __launch_bounds__(256) void k_rows_fused(const RowFusedArgs a) {
             }
         }
     }
-    if (EP == EP_LINESEARCH) {
+    if (LS) {
 #pragma unroll
         for (int i = 0; i < NACC; ++i) acc[i] = acc2[i].x + acc2[i].y;
     }
-    if (EP == EP_ACCUM_I || EP == EP_ACCUM_P || EP == EP_CROSS) return;
+    if (EP == EP_ACCUM_I || EP == EP_CROSS) return;
     // ---- block reduction (float partials -> double), one atomic per value per workgroup
     const int lane = tid & 63, wave = tid >> 6;
 #pragma unroll
@@ -415,59 +454,29 @@ __global__ __launch_bounds__(256) void k_rows_fused(const RowFusedArgs a) {
     __syncthreads();
     if (tid < NACC) {
         const double x = red[tid] + red[NACC + tid] + red[2 * NACC + tid] + red[3 * NACC + tid];
-        if (EP != EP_LINESEARCH || tid < a.ncand || tid == kMaxCand)
-            atomicAdd(a.sums + (EP == EP_LINESEARCH && tid == kMaxCand ? a.ncand : tid), x);
+        if (!LS || tid < a.ncand || tid == kMaxCand)
+            atomicAdd(a.sums + (LS && tid == kMaxCand ? a.ncand : tid), x);
     }
 }
 
-// elementwise reductions over stored arrays (multi-mode CG path): no DFT involved
-//   MODE 0: sums += { sum sqrt(I d), sum I }                                   (ptycho.py:342-343)
-//   MODE 1: costs[j] += sum (sqrt|p1 + y_j^2 p2 + y_j p3| - sqrt d)^2, costs[ncand] += f(p1)
-constexpr int kArrCand = 32;   // candidates per pass of the array line search
-
-template <int MODE>
-__global__ __launch_bounds__(256) void k_array_reduce(const float* __restrict__ p1, const float* __restrict__ p2,
-                                                      const float* __restrict__ p3, const float* __restrict__ d,
-                                                      const long long n, const float gamma0, const int ncand,
-                                                      double* __restrict__ sums) {
-    constexpr int NACC = MODE == 0 ? 2 : kArrCand + 1;
-    __shared__ double red[4 * NACC];
-    float acc[NACC];
-#pragma unroll
-    for (int i = 0; i < NACC; ++i) acc[i] = 0.0f;
+// sums += { sum sqrt(I d), sum I } over stored float32 arrays (multi-mode intensity, ptycho.py:342-343)
+__global__ __launch_bounds__(256) void k_array_stats(const float* __restrict__ inten, const float* __restrict__ d,
+                                                     const long long n, double* __restrict__ sums) {
+    __shared__ double red[4 * 2];
+    float acc[2] = {0.0f, 0.0f};
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
-        const float dd = d[i];
-        if (MODE == 0) {
-            const float I = p1[i];
-            acc[0] += fsqrt(I * dd);
-            acc[1] += I;
-        } else {
-            const float a1 = p1[i], a2 = p2[i], a3 = p3[i];
-            const float sd = fsqrt(dd);
-            float df = fsqrt(fabsf(a1)) - sd;
-            acc[kArrCand] += df * df;
-            float gam = gamma0;
-#pragma unroll
-            for (int j = 0; j < kArrCand; ++j) {
-                if (j < ncand) {
-                    df = fsqrt(fabsf(a1 + (gam * gam) * a2 + gam * a3)) - sd;
-                    acc[j] += df * df;
-                }
-                gam *= 0.5f;
-            }
-        }
+        const float I = inten[i];
+        acc[0] += fsqrt(I * d[i]);
+        acc[1] += I;
     }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 #pragma unroll
-    for (int i = 0; i < NACC; ++i) {
+    for (int i = 0; i < 2; ++i) {
         double x = (double)acc[i];
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) x += __shfl_down(x, off, 64);
-        if (lane == 0) red[wave * NACC + i] = x;
+        if (lane == 0) red[wave * 2 + i] = x;
     }
     __syncthreads();
-    if (tid < NACC) {
-        const double x = red[tid] + red[NACC + tid] + red[2 * NACC + tid] + red[3 * NACC + tid];
-        if (MODE == 0 || tid < ncand || tid == kArrCand) atomicAdd(sums + (MODE == 1 && tid == kArrCand ? ncand : tid), x);
-    }
+    if (tid < 2) atomicAdd(sums + tid, red[tid] + red[2 + tid] + red[4 + tid] + red[6 + tid]);
 }

@@ -78,7 +78,8 @@ struct ptycho_handle_s {
     int* order = nullptr;
     void* sort_tmp = nullptr;
     size_t sort_tmp_bytes = 0;
-    c32* work[2] = {nullptr, nullptr};   // CG work buffers (column-pass intermediates), all positions
+    static constexpr int kSlots = 2 * kMaxModes;
+    c32* work[kSlots] = {};   // CG work buffers (column-pass intermediates), all positions; 0/1 + per-mode pairs
     void* zoom_phase = nullptr;           // registration: per-pattern phases + whole-pixel shifts
     int use_window = 1;       // 0: direct-atomics object adjoint (k_cols<ADJ_OBJ>)
     int use_team = 0;         // 1: forward operator as one persistent XCD-team launch (experimental)
@@ -533,8 +534,9 @@ int do_fft2(ptycho_handle h, c32* dst, const c32* src, long long nbatch, int dir
 
 
 // ---- CG-stage helpers ----------------------------------------------------------------
+inline bool slot_ready(ptycho_handle h, int slot) { return slot >= 0 && slot < ptycho_handle_s::kSlots && h->work[slot]; }
 int ensure_work(ptycho_handle h, int slot) {
-    if (slot < 0 || slot > 1) return fail(PTYCHO_ERR_ARG, "work slot must be 0 or 1");
+    if (slot < 0 || slot >= ptycho_handle_s::kSlots) return fail(PTYCHO_ERR_ARG, "work slot out of range");
     if (!h->work[slot]) {
         const size_t total = (size_t)h->ge.ptheta * h->ge.nscan;
         HIP_TRY(hipMalloc((void**)&h->work[slot], total * h->ge.ndet * h->ge.ndet * sizeof(c32)));
@@ -609,7 +611,7 @@ int do_cg_rows(ptycho_handle h, RowFusedArgs a, hipStream_t st) {
     long long nb = (a.nrows + B - 1) / B;
     long long grid = nb < (long long)h->n_cu * 8 ? nb : (long long)h->n_cu * 8;
     {
-        ProfSpan ps(h, EP == EP_STATS ? K_ROWS_STATS : EP == EP_PROJECT ? K_ROWS_PROJECT : EP == EP_LINESEARCH ? K_ROWS_LINESEARCH : EP == EP_CROSS ? K_ROWS_CROSS : K_ROWS_ACCUM, st);
+        ProfSpan ps(h, EP == EP_STATS ? K_ROWS_STATS : EP == EP_PROJECT ? K_ROWS_PROJECT : (EP == EP_LINESEARCH || EP == EP_LINESEARCH_M) ? K_ROWS_LINESEARCH : EP == EP_CROSS ? K_ROWS_CROSS : K_ROWS_ACCUM, st);
         hipLaunchKernelGGL((k_rows_fused<N, EP>), dim3((unsigned)grid), dim3(256), 0, st, a);
     }
     HIP_TRY(hipGetLastError());
@@ -666,9 +668,9 @@ int alloc_sort(ptycho_handle h) {
 }
 
 void release(ptycho_handle h) {
-    void* ptrs[] = {h->table, h->scratch, h->keys_a, h->keys_b, h->vals_a, h->order, h->sort_tmp, h->work[0], h->work[1], h->ring, h->ctrl, h->zoom_phase};
+    void* ptrs[] = {h->table, h->scratch, h->keys_a, h->keys_b, h->vals_a, h->order, h->sort_tmp, h->ring, h->ctrl, h->zoom_phase};
     h->ring = nullptr; h->ctrl = nullptr; h->zoom_phase = nullptr;
-    h->work[0] = nullptr; h->work[1] = nullptr;
+    for (auto& w : h->work) { if (w) (void)hipFree(w); w = nullptr; }
     for (void* q : ptrs)
         if (q) (void)hipFree(q);
     h->table = nullptr; h->scratch = nullptr; h->keys_a = nullptr; h->keys_b = nullptr;
@@ -867,7 +869,7 @@ int ptycho_cg_adj_cols(ptycho_handle h, int slot, void* f, const void* scan, voi
     if (rc) return rc;
     if (!f || !scan || !prb) return fail(PTYCHO_ERR_ARG, "null operand");
     if (flg != 0 && flg != 1) return fail(PTYCHO_ERR_ARG, "flg must be 0 (object) or 1 (probe)");
-    if (slot < 0 || slot > 1 || !h->work[slot]) return fail(PTYCHO_ERR_ARG, "work slot is empty");
+    if (!slot_ready(h, slot)) return fail(PTYCHO_ERR_ARG, "work slot is empty");
     hipStream_t st = (hipStream_t)stream;
     PTY_DISPATCH(h->ge.ndet, (do_cg_adj_cols<NN>(h, slot, (c32*)f, (const float*)scan, (c32*)prb, flg, st)));
 }
@@ -876,7 +878,7 @@ int ptycho_cg_stats(ptycho_handle h, int slot, const void* data, double* sums, v
     int rc = check_handle(h);
     if (rc) return rc;
     if (!data || !sums) return fail(PTYCHO_ERR_ARG, "null operand");
-    if (slot < 0 || slot > 1 || !h->work[slot]) return fail(PTYCHO_ERR_ARG, "work slot is empty");
+    if (!slot_ready(h, slot)) return fail(PTYCHO_ERR_ARG, "work slot is empty");
     RowFusedArgs a{};
     a.s1 = h->work[slot]; a.data = (const float*)data; a.sums = sums;
     hipStream_t st = (hipStream_t)stream;
@@ -888,7 +890,7 @@ int ptycho_cg_project(ptycho_handle h, int src_slot, int dst_slot, const void* d
     int rc = check_handle(h);
     if (rc) return rc;
     if (!data || !cost) return fail(PTYCHO_ERR_ARG, "null operand");
-    if (src_slot < 0 || src_slot > 1 || !h->work[src_slot]) return fail(PTYCHO_ERR_ARG, "work slot is empty");
+    if (!slot_ready(h, src_slot)) return fail(PTYCHO_ERR_ARG, "work slot is empty");
     rc = ensure_work(h, dst_slot);
     if (rc) return rc;
     RowFusedArgs a{};
@@ -903,7 +905,7 @@ int ptycho_cg_linesearch(ptycho_handle h, int slot1, int slot2, const void* data
     if (rc) return rc;
     if (!data || !costs) return fail(PTYCHO_ERR_ARG, "null operand");
     if (ncand < 1 || ncand > kMaxCand) return fail(PTYCHO_ERR_ARG, "ncand must be in [1, 16]");
-    if (slot1 < 0 || slot1 > 1 || slot2 < 0 || slot2 > 1 || !h->work[slot1] || !h->work[slot2])
+    if (!slot_ready(h, slot1) || !slot_ready(h, slot2))
         return fail(PTYCHO_ERR_ARG, "work slot is empty");
     RowFusedArgs a{};
     a.s1 = h->work[slot1]; a.s2 = h->work[slot2]; a.data = (const float*)data; a.sums = costs; a.ab = ab;
@@ -913,44 +915,51 @@ int ptycho_cg_linesearch(ptycho_handle h, int slot1, int slot2, const void* data
 }
 
 int ptycho_cg_project_multi(ptycho_handle h, int src_slot, int dst_slot, const void* data, const void* inten,
-                            const double* ab, double* cost, void* stream) {
+                            const double* ab, int slot_unscaled, double* cost, void* stream) {
     int rc = check_handle(h);
     if (rc) return rc;
     if (!data || !cost || !inten) return fail(PTYCHO_ERR_ARG, "null operand");
-    if (src_slot < 0 || src_slot > 1 || !h->work[src_slot]) return fail(PTYCHO_ERR_ARG, "work slot is empty");
+    if (!slot_ready(h, src_slot)) return fail(PTYCHO_ERR_ARG, "work slot is empty");
     rc = ensure_work(h, dst_slot);
     if (rc) return rc;
     RowFusedArgs a{};
     a.s1 = h->work[src_slot]; a.out = h->work[dst_slot]; a.data = (const float*)data; a.sums = cost; a.ab = ab;
     a.inten = (const float*)inten;
+    a.first = slot_unscaled ? 1 : 0;
     hipStream_t st = (hipStream_t)stream;
     PTY_DISPATCH(h->ge.ndet, (do_cg_rows<NN, EP_PROJECT>(h, a, st)));
+}
+
+int ptycho_cg_linesearch_modes(ptycho_handle h, int mode0, int nmodes, const void* data, const void* inten,
+                               const double* ab, double gamma0, int ncand, double* costs, void* stream) {
+    int rc = check_handle(h);
+    if (rc) return rc;
+    if (!data || !costs) return fail(PTYCHO_ERR_ARG, "null operand");
+    if (mode0 < 0 || nmodes < 1 || mode0 + nmodes > kMaxModes) return fail(PTYCHO_ERR_ARG, "modes must lie in [0, 8)");
+    if (ncand < 1 || ncand > kMaxCand) return fail(PTYCHO_ERR_ARG, "ncand must be in [1, 16]");
+    RowFusedArgs a{};
+    for (int k = 0; k < 2 * nmodes; ++k) {
+        if (!slot_ready(h, 2 * mode0 + k)) return fail(PTYCHO_ERR_ARG, "work slot is empty");
+        a.sm[k] = h->work[2 * mode0 + k];
+    }
+    a.nmodes = nmodes;
+    a.data = (const float*)data; a.inten = (const float*)inten; a.sums = costs; a.ab = ab;
+    a.gamma0 = (float)gamma0; a.ncand = ncand;
+    hipStream_t st = (hipStream_t)stream;
+    PTY_DISPATCH(h->ge.ndet, (do_cg_rows<NN, EP_LINESEARCH_M>(h, a, st)));
 }
 
 int ptycho_cg_accum_intensity(ptycho_handle h, int slot, void* inten, int first, void* stream) {
     int rc = check_handle(h);
     if (rc) return rc;
     if (!inten) return fail(PTYCHO_ERR_ARG, "null operand");
-    if (slot < 0 || slot > 1 || !h->work[slot]) return fail(PTYCHO_ERR_ARG, "work slot is empty");
+    if (!slot_ready(h, slot)) return fail(PTYCHO_ERR_ARG, "work slot is empty");
     RowFusedArgs a{};
     a.s1 = h->work[slot]; a.acc1 = (float*)inten; a.first = first;
     hipStream_t st = (hipStream_t)stream;
     PTY_DISPATCH(h->ge.ndet, (do_cg_rows<NN, EP_ACCUM_I>(h, a, st)));
 }
 
-int ptycho_cg_accum_terms(ptycho_handle h, int slot1, int slot2, void* p1, void* p2, void* p3, int first,
-                          const double* ab, void* stream) {
-    int rc = check_handle(h);
-    if (rc) return rc;
-    if (!p1 || !p2 || !p3) return fail(PTYCHO_ERR_ARG, "null operand");
-    if (slot1 < 0 || slot1 > 1 || slot2 < 0 || slot2 > 1 || !h->work[slot1] || !h->work[slot2])
-        return fail(PTYCHO_ERR_ARG, "work slot is empty");
-    RowFusedArgs a{};
-    a.s1 = h->work[slot1]; a.s2 = h->work[slot2]; a.acc1 = (float*)p1; a.acc2 = (float*)p2; a.acc3 = (float*)p3;
-    a.first = first; a.ab = ab;
-    hipStream_t st = (hipStream_t)stream;
-    PTY_DISPATCH(h->ge.ndet, (do_cg_rows<NN, EP_ACCUM_P>(h, a, st)));
-}
 
 int ptycho_cg_array_stats(ptycho_handle h, const void* inten, const void* data, double* sums, void* stream) {
     int rc = check_handle(h);
@@ -960,29 +969,13 @@ int ptycho_cg_array_stats(ptycho_handle h, const void* inten, const void* data, 
     hipStream_t st = (hipStream_t)stream;
     {
         ProfSpan ps(h, K_ARRAY_REDUCE, st);
-        hipLaunchKernelGGL((k_array_reduce<0>), dim3((unsigned)(h->n_cu * 8)), dim3(256), 0, st, (const float*)inten,
-                           (const float*)nullptr, (const float*)nullptr, (const float*)data, n, 0.0f, 0, sums);
+        hipLaunchKernelGGL(k_array_stats, dim3((unsigned)(h->n_cu * 8)), dim3(256), 0, st, (const float*)inten,
+                           (const float*)data, n, sums);
     }
     HIP_TRY(hipGetLastError());
     return PTYCHO_OK;
 }
 
-int ptycho_cg_array_costs(ptycho_handle h, const void* p1, const void* p2, const void* p3, const void* data,
-                          double gamma0, int ncand, double* costs, void* stream) {
-    int rc = check_handle(h);
-    if (rc) return rc;
-    if (!p1 || !p2 || !p3 || !data || !costs) return fail(PTYCHO_ERR_ARG, "null operand");
-    if (ncand < 1 || ncand > kArrCand) return fail(PTYCHO_ERR_ARG, "ncand must be in [1, 32]");
-    const long long n = (long long)h->ge.ptheta * h->ge.nscan * h->ge.ndet * h->ge.ndet;
-    hipStream_t st = (hipStream_t)stream;
-    {
-        ProfSpan ps(h, K_ARRAY_REDUCE, st);
-        hipLaunchKernelGGL((k_array_reduce<1>), dim3((unsigned)(h->n_cu * 8)), dim3(256), 0, st, (const float*)p1,
-                           (const float*)p2, (const float*)p3, (const float*)data, n, (float)gamma0, ncand, costs);
-    }
-    HIP_TRY(hipGetLastError());
-    return PTYCHO_OK;
-}
 
 int ptycho_fft2(ptycho_handle h, void* dst, const void* src, size_t nbatch, int dir, void* stream) {
     int rc = check_handle(h);
@@ -1021,7 +1014,7 @@ extern "C" int ptycho_cg_cross(ptycho_handle h, int slot1, int slot2, double gam
     if (h->ge.nprb != h->ge.ndet) {
         // with a padded probe the zero columns of the slots are not materialised; the row pass masks them
     }
-    if (slot1 < 0 || slot1 > 1 || slot2 < 0 || slot2 > 1 || !h->work[slot1] || !h->work[slot2])
+    if (!slot_ready(h, slot1) || !slot_ready(h, slot2))
         return fail(PTYCHO_ERR_ARG, "work slot is empty");
     RowFusedArgs a{};
     a.s1 = h->work[slot1]; a.s2 = h->work[slot2]; a.out = h->work[slot2]; a.ip = (c32*)image_product;
@@ -1034,7 +1027,7 @@ extern "C" int ptycho_cg_argmax(ptycho_handle h, int slot, void* best, void* str
     int rc = check_handle(h);
     if (rc) return rc;
     if (!best) return fail(PTYCHO_ERR_ARG, "null operand");
-    if (slot < 0 || slot > 1 || !h->work[slot]) return fail(PTYCHO_ERR_ARG, "work slot is empty");
+    if (!slot_ready(h, slot)) return fail(PTYCHO_ERR_ARG, "work slot is empty");
     hipStream_t st = (hipStream_t)stream;
     PTY_DISPATCH(h->ge.ndet, (do_cg_argmax<NN>(h, slot, (unsigned long long*)best, st)));
 }

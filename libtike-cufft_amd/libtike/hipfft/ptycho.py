@@ -683,23 +683,25 @@ class CGPtychoSolver(PtychoHIP):
         return {"psi": psi, "probe": probe}
 
     # -- fused multi-mode gaussian loop ----------------------------------------------------
-    def _array_line_search(self, p1, p2, p3, data, costs, which="psi"):
-        """All trials of ``line_search_sqr`` (ptycho.py:253-281) on stored p1, p2, p3, up to 32
-        step lengths per pass; ``costs`` has 33 entries.  The number priced per pass follows the
-        last accepted index of the same search (``which``), as in ``_fused_line_search``."""
+    def _modes_line_search(self, mode0, nmodes, data, inten, ab, costs, which):
+        """All trials of ``line_search_sqr`` (ptycho.py:253-281) with p1, p2, p3 summed over the
+        mode pairs (slot 2k, slot 2k+1) in the row pass's registers (``ptycho_cg_linesearch_modes``);
+        pass sizing as in ``_fused_line_search``."""
         hints = self.__dict__.setdefault("_ls_hint", {})
-        nc = min(32, max(2, hints.get(which, 14) + 2))
+        ncand = min(16, max(2, hints.get(which, 14) + 2))
         gamma0 = 1.0
         tried = 0
         while True:
             costs.zero_()
-            nat.check(nat.cg_array_costs(self._h, _ptr(p1), _ptr(p2), _ptr(p3), _ptr(data), gamma0, nc,
-                                         _ptr(costs), _stream()))
+            nat.check(nat.cg_linesearch_modes(self._h, mode0, nmodes, _ptr(data),
+                                              _ptr(inten) if inten is not None else None,
+                                              _ptr(ab) if ab is not None else None,
+                                              gamma0, ncand, _ptr(costs), _stream()))
             self._allreduce(costs)
             c = costs.to(torch.float32).cpu().numpy()
             step = gamma0
-            for j in range(nc):
-                if not (c[j] > c[nc]):
+            for j in range(ncand):
+                if not (c[j] > c[ncand]):
                     hints[which] = tried + j
                     return step
                 if step < 1e-32:
@@ -708,14 +710,17 @@ class CGPtychoSolver(PtychoHIP):
                     return 0
                 step *= 0.5
             gamma0 = step
-            tried += nc
-            nc = 32
+            tried += ncand
+            ncand = 16
 
     def _run_fused_multi(self, data, psi, scan, probe, piter, recover_prb):
-        """``CGPtychoSolver.run`` (ptycho.py:283-488), gaussian model, any number of
-        incoherent probe modes.  The summed intensity and the line-search terms are kept as
-        float32 arrays (they are sums over modes *before* the nonlinearity); every farplane
-        itself stays in the row pass's registers (C ABI ``ptycho_cg_*``)."""
+        """``CGPtychoSolver.run`` (ptycho.py:283-488), gaussian model, 2..8 incoherent probe
+        modes.  Every mode k owns a pair of work slots: 2k holds the column pass of
+        fwd(psi, probe_k) -- made once per step and shared by the intensity sum, the
+        projection and the line search (the probe rescale a/b is linear and applied on the
+        fly, as in the single-mode loop) -- and 2k+1 the projected residual, then the column
+        pass of fwd(dpsi, probe_k).  The summed intensity is a float32 array; the line-search
+        terms p1, p2, p3 are summed over the modes in registers (C ABI ``ptycho_cg_*``)."""
         dev = data.device
         M = probe.shape[1]
         data = self._operand(data, torch.float32, (self.ptheta, self.nscan, self.ndet, self.ndet), "data")
@@ -728,13 +733,13 @@ class CGPtychoSolver(PtychoHIP):
         scratch_cost = torch.zeros(1, dtype=torch.float64, device=dev)
         costs = torch.zeros(33, dtype=torch.float64, device=dev)
         inten = torch.empty_like(data)
-        p1, p2, p3 = torch.empty_like(data), torch.empty_like(data), torch.empty_like(data)
         mode = lambda arr, k: arr[:, k].contiguous()
+        A = lambda k: 2 * k          # column pass of fwd(psi, probe_k)
+        B = lambda k: 2 * k + 1      # residual of mode k, then column pass of fwd(direction, .)
 
-        def total_intensity(slot):
+        def sum_intensity():
             for k in range(M):
-                self._cg_fwd_cols(slot, psi, scan, mode(probe, k))
-                nat.check(nat.cg_accum_intensity(self._h, slot, _ptr(inten), int(k == 0), _stream()))
+                nat.check(nat.cg_accum_intensity(self._h, A(k), _ptr(inten), int(k == 0), _stream()))
 
         dpsi = gradpsi0 = None
         dprb = gradprb0 = gradprb = None
@@ -744,7 +749,9 @@ class CGPtychoSolver(PtychoHIP):
                   "iteration, step size object, step size probe, function min")
         for i in range(piter):
             # 1) object step ------------------------------------------------------------
-            total_intensity(0)                                                  # :329-333
+            for k in range(M):                                                  # :329-333
+                self._cg_fwd_cols(A(k), psi, scan, mode(probe, k))
+            sum_intensity()
             sums.zero_()
             nat.check(nat.cg_array_stats(self._h, _ptr(inten), _ptr(data), _ptr(sums), _stream()))
             self._allreduce(sums)
@@ -754,21 +761,19 @@ class CGPtychoSolver(PtychoHIP):
             cost.zero_()
             for k in range(M):                                                  # :349-356
                 pk = mode(probe, k)
-                self._cg_fwd_cols(0, psi, scan, pk)
-                nat.check(nat.cg_project_multi(self._h, 0, 1, _ptr(data), _ptr(inten), _ptr(sums),
+                # slot A(k) was made with the probe before its rescale: fpsi = (g s)(1/s)
+                nat.check(nat.cg_project_multi(self._h, A(k), B(k), _ptr(data), _ptr(inten), _ptr(sums), 1,
                                                _ptr(cost if k == 0 else scratch_cost), _stream()))
                 g = torch.zeros_like(gradpsi)
-                nat.check(nat.cg_adj_cols(self._h, 1, _ptr(g), _ptr(scan), _ptr(pk), 0, _stream()))
+                nat.check(nat.cg_adj_cols(self._h, B(k), _ptr(g), _ptr(scan), _ptr(pk), 0, _stream()))
                 gradpsi += g / (torch.max(torch.abs(pk)) ** 2)
             self._allreduce(gradpsi)
             dpsi = _dy_direction(i, gradpsi, gradpsi0, dpsi)
             gradpsi0 = gradpsi
             for k in range(M):                                                  # :383-391
-                pk = mode(probe, k)
-                self._cg_fwd_cols(0, psi, scan, pk)
-                self._cg_fwd_cols(1, dpsi, scan, pk)
-                nat.check(nat.cg_accum_terms(self._h, 0, 1, _ptr(p1), _ptr(p2), _ptr(p3), int(k == 0), None, _stream()))
-            gammapsi = 0.5 * self._array_line_search(p1, p2, p3, data, costs)
+                self._cg_fwd_cols(B(k), dpsi, scan, mode(probe, k))
+            # t1_k = (a/b) * slot A(k) (old probe), t2_k = slot B(k) (rescaled probe)
+            gammapsi = 0.5 * self._modes_line_search(0, M, data, None, sums, costs, "psi")
 
             if i > 0:                                                           # :398-403
                 scan[0, :] += self._position_shifts(psi, dpsi, gammapsi, scan, probe).to(scan.dtype)
@@ -781,13 +786,16 @@ class CGPtychoSolver(PtychoHIP):
                     gradprb0 = probe * 0
                     dprb = probe * 0
                 for m in range(M):
-                    self._cg_fwd_cols(0, psi, scan, mode(probe, m))             # fprb
-                    total_intensity(1)                                          # absfprb (= p1 below)
+                    # slots A(k) = fwd(psi, probe_k) for the current psi and probes: all of them
+                    # after the object step, then only the mode that was just updated
+                    for k in (range(M) if m == 0 else (m - 1,)):
+                        self._cg_fwd_cols(A(k), psi, scan, mode(probe, k))
+                    sum_intensity()                                             # absfprb (= p1 below)
                     scratch_cost.zero_()
-                    nat.check(nat.cg_project_multi(self._h, 0, 1, _ptr(data), _ptr(inten), None,
+                    nat.check(nat.cg_project_multi(self._h, A(m), B(m), _ptr(data), _ptr(inten), None, 0,
                                                    _ptr(scratch_cost), _stream()))
                     g = torch.zeros((self.ptheta, self.nprb, self.nprb), dtype=torch.complex64, device=dev)
-                    nat.check(nat.cg_adj_cols(self._h, 1, _ptr(psi), _ptr(scan), _ptr(g), 1, _stream()))
+                    nat.check(nat.cg_adj_cols(self._h, B(m), _ptr(psi), _ptr(scan), _ptr(g), 1, _stream()))
                     self._allreduce(g)
                     gradprb[:, m] = g / torch.max(torch.abs(psi)) ** 2 / nscan_total * M
                     if i == 0:
@@ -798,10 +806,9 @@ class CGPtychoSolver(PtychoHIP):
                             / (torch.sum(torch.conj(dprb[:, m]) * (gradprb[:, m] - gradprb0[:, m])))
                             * dprb[:, m])
                     gradprb0[:, m] = gradprb[:, m]
-                    self._cg_fwd_cols(0, psi, scan, mode(probe, m))
-                    self._cg_fwd_cols(1, psi, scan, mode(dprb, m))
-                    nat.check(nat.cg_accum_terms(self._h, 0, 1, _ptr(p1), _ptr(p2), _ptr(p3), 1, None, _stream()))
-                    gammaprb = 0.5 * self._array_line_search(inten, p2, p3, data, costs, which="prb%d" % m)
+                    self._cg_fwd_cols(B(m), psi, scan, mode(dprb, m))
+                    # p1 = summed intensity, p2 = |fwd(psi, dprb_m)|^2, p3 = 2 Re(fwd(psi, probe_m) conj(.))
+                    gammaprb = 0.5 * self._modes_line_search(m, 1, data, inten, None, costs, "prb%d" % m)
                     probe[:, m] = probe[:, m] + gammaprb * dprb[:, m]
 
             if i % self.log_every == 0:
@@ -823,7 +830,8 @@ class CGPtychoSolver(PtychoHIP):
         if self.fused and model == "gaussian":
             if nmodes == 1:
                 return self._run_fused(data, psi, scan, probe, piter, recover_prb)
-            return self._run_fused_multi(data, psi, scan, probe, piter, recover_prb)
+            if nmodes <= 8:          # one pair of work slots per mode (ptycho_hip.h)
+                return self._run_fused_multi(data, psi, scan, probe, piter, recover_prb)
         nscan_total = self._nscan_total()
 
         def minf(fpsi):
