@@ -102,16 +102,15 @@ int ptycho_cg_linesearch(ptycho_handle h, int slot1, int slot2, const void* data
 /* Multi-mode variants (ptycho.py:330-333,349-356,386-391,425-434 loop over probe modes):
  * the summed intensity is a float32 array [ptheta][nscan][ndet][ndet] owned by the caller;
  * each mode k has its own pair of work slots (2k, 2k+1).
- *   ptycho_cg_accum_intensity  inten (first ? = : +=) |g|^2 of the slot
- *   ptycho_cg_array_stats      sums += { sum sqrt(inten d), sum inten }
+ *   ptycho_cg_intensity_modes  inten = sum_k |g_k|^2 over the slots 2k, k < nmodes (inten may be NULL), and,
+ *                              if sums is given, sums += { sum sqrt(inten d), sum inten }: one pass
  *   ptycho_cg_project_multi    as ptycho_cg_project with I = inten * (a/b)^2; slot_unscaled = 0: the slot was
  *                              made with the rescaled probe, 1: with the probe before its rescale
  *   ptycho_cg_linesearch_modes as ptycho_cg_linesearch with p1,p2,p3 summed in registers over the mode
  *                              pairs (slot 2k, slot 2k+1), mode0 <= k < mode0 + nmodes <= 8 (no arrays); p1 = inten if given
  */
-int ptycho_cg_accum_intensity(ptycho_handle h, int slot, void* inten, int first, void* stream);
-int ptycho_cg_array_stats(ptycho_handle h, const void* inten, const void* data, double* sums,
-                          void* stream);
+int ptycho_cg_intensity_modes(ptycho_handle h, int nmodes, void* inten, const void* data, double* sums,
+                              void* stream);
 int ptycho_cg_project_multi(ptycho_handle h, int src_slot, int dst_slot, const void* data,
                             const void* inten, const double* ab, int slot_unscaled, double* cost,
                             void* stream);

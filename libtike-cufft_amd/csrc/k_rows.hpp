@@ -163,7 +163,7 @@ __global__ __launch_bounds__(256) void k_rows_split(const RowArgs a) {
 __device__ __forceinline__ float fsqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
 __device__ __forceinline__ float frcp(float x) { return __builtin_amdgcn_rcpf(x); }
 
-enum RowEp { EP_STATS = 1, EP_PROJECT = 2, EP_LINESEARCH = 3, EP_ACCUM_I = 4, EP_CROSS = 6, EP_LINESEARCH_M = 7 };
+enum RowEp { EP_STATS = 1, EP_PROJECT = 2, EP_LINESEARCH = 3, EP_CROSS = 6, EP_LINESEARCH_M = 7, EP_STATS_M = 8 };
 constexpr int kMaxModes = 8;   // EP_LINESEARCH_M: slot pairs (2k, 2k+1), k < nmodes
 constexpr int kMaxCand = 16;
 
@@ -181,7 +181,7 @@ struct RowFusedArgs {
     int xa, xb;          // columns outside [xa, xb) of the inputs are zero (never written)
     // multi-mode variants (arrays are float32 [positions][ndet][ndet])
     const float* inten;  // EP_PROJECT: summed intensity of all modes (nullptr: single mode, |g|^2)
-    float* acc1;         // EP_ACCUM_I: intensity
+    float* acc1;         // EP_STATS_M: summed intensity (may be null)
     int first;           // 1: overwrite the arrays, 0: add to them; EP_PROJECT with inten: 1 = the slot was
                          // made with the probe BEFORE its rescale (fp = (g s)(1/s) as in the single-mode path)
     // EP_LINESEARCH_M: t1_k = s * DFT_x(sm[2k]), t2_k = DFT_x(sm[2k+1]); p1 = inten if given, else sum_k |t1_k|^2
@@ -198,7 +198,7 @@ __global__ __launch_bounds__(256) void k_rows_fused(const RowFusedArgs a) {
     constexpr int E = P::E, T = P::T, B = 256 / T;
     constexpr int LAST = P::NSTEP - 1;
     constexpr bool LS = EP == EP_LINESEARCH || EP == EP_LINESEARCH_M;
-    constexpr int NACC = EP == EP_STATS ? 2 : (LS ? kMaxCand + 1 : 1);
+    constexpr int NACC = (EP == EP_STATS || EP == EP_STATS_M) ? 2 : (LS ? kMaxCand + 1 : 1);
     __shared__ c32 lds[P::NSTEP > 1 ? B * L::FS : 1];
     __shared__ double red[4 * NACC];
     __shared__ c32 stash[(EP == EP_CROSS || EP == EP_LINESEARCH_M) ? E * 256 : 1];
@@ -252,7 +252,7 @@ __global__ __launch_bounds__(256) void k_rows_fused(const RowFusedArgs a) {
         const size_t boff = (size_t)batch * B * N;
         const unsigned fN = (unsigned)(f * N);
         c32 v[E], g1[E];
-        const c32* __restrict__ first_src = EP == EP_LINESEARCH_M ? a.sm[0] : a.s1;
+        const c32* __restrict__ first_src = (EP == EP_LINESEARCH_M || EP == EP_STATS_M) ? a.sm[0] : a.s1;
         fft.template load<0>(v, j0, [&](int i) { return (ok && i >= a.xa && i < a.xb) ? __builtin_nontemporal_load(first_src + boff + (fN + (unsigned)i)) : zero; });
         fwd_row(v, g1);
         float d[E];
@@ -309,13 +309,30 @@ __global__ __launch_bounds__(256) void k_rows_fused(const RowFusedArgs a) {
                 acc[0] += fsqrt(I * d[m]);
                 acc[1] += I;
             }
-        } else if (EP == EP_ACCUM_I) {
-            if (ok) {
+        } else if (EP == EP_STATS_M) {
+            // summed intensity of nmodes slots sm[0..nmodes) (ptycho.py:329-333): written to acc1 if
+            // given, and the statistics of :342-343 added to sums if given -- one pass instead of
+            // one accumulate pass per mode plus an array reduction
+            float I[E];
+#pragma unroll
+            for (int m = 0; m < E; ++m) I[m] = g1[m].x * g1[m].x + g1[m].y * g1[m].y;
+            for (int k = 1; k < a.nmodes; ++k) {
+                const c32* __restrict__ src = a.sm[k];
+                fft.template load<0>(v, j0, [&](int i) { return (ok && i >= a.xa && i < a.xb) ? __builtin_nontemporal_load(src + boff + (fN + (unsigned)i)) : zero; });
+                fwd_row(v, g1);
+#pragma unroll
+                for (int m = 0; m < E; ++m) I[m] += g1[m].x * g1[m].x + g1[m].y * g1[m].y;
+            }
+            if (a.acc1 && ok) {
+#pragma unroll
+                for (int m = 0; m < E; ++m) a.acc1[boff + (fN + (unsigned)(j0 + m * T))] = I[m];
+            }
+            if (a.sums) {
+                load_data();
 #pragma unroll
                 for (int m = 0; m < E; ++m) {
-                    const float I = g1[m].x * g1[m].x + g1[m].y * g1[m].y;
-                    float* o = a.acc1 + boff + (fN + (unsigned)(j0 + m * T));
-                    *o = a.first ? I : *o + I;
+                    acc[0] += fsqrt(I[m] * d[m]);
+                    acc[1] += I[m];
                 }
             }
         } else if (EP == EP_PROJECT) {
@@ -441,7 +458,8 @@ __global__ __launch_bounds__(256) void k_rows_fused(const RowFusedArgs a) {
 #pragma unroll
         for (int i = 0; i < NACC; ++i) acc[i] = acc2[i].x + acc2[i].y;
     }
-    if (EP == EP_ACCUM_I || EP == EP_CROSS) return;
+    if (EP == EP_CROSS) return;
+    if (EP == EP_STATS_M && !a.sums) return;
     // ---- block reduction (float partials -> double), one atomic per value per workgroup
     const int lane = tid & 63, wave = tid >> 6;
 #pragma unroll
@@ -457,26 +475,4 @@ __global__ __launch_bounds__(256) void k_rows_fused(const RowFusedArgs a) {
         if (!LS || tid < a.ncand || tid == kMaxCand)
             atomicAdd(a.sums + (LS && tid == kMaxCand ? a.ncand : tid), x);
     }
-}
-
-// sums += { sum sqrt(I d), sum I } over stored float32 arrays (multi-mode intensity, ptycho.py:342-343)
-__global__ __launch_bounds__(256) void k_array_stats(const float* __restrict__ inten, const float* __restrict__ d,
-                                                     const long long n, double* __restrict__ sums) {
-    __shared__ double red[4 * 2];
-    float acc[2] = {0.0f, 0.0f};
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
-        const float I = inten[i];
-        acc[0] += fsqrt(I * d[i]);
-        acc[1] += I;
-    }
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        double x = (double)acc[i];
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) x += __shfl_down(x, off, 64);
-        if (lane == 0) red[wave * 2 + i] = x;
-    }
-    __syncthreads();
-    if (tid < 2) atomicAdd(sums + tid, red[tid] + red[2 + tid] + red[4 + tid] + red[6 + tid]);
 }

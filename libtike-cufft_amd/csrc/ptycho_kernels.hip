@@ -611,7 +611,7 @@ int do_cg_rows(ptycho_handle h, RowFusedArgs a, hipStream_t st) {
     long long nb = (a.nrows + B - 1) / B;
     long long grid = nb < (long long)h->n_cu * 8 ? nb : (long long)h->n_cu * 8;
     {
-        ProfSpan ps(h, EP == EP_STATS ? K_ROWS_STATS : EP == EP_PROJECT ? K_ROWS_PROJECT : (EP == EP_LINESEARCH || EP == EP_LINESEARCH_M) ? K_ROWS_LINESEARCH : EP == EP_CROSS ? K_ROWS_CROSS : K_ROWS_ACCUM, st);
+        ProfSpan ps(h, (EP == EP_STATS || EP == EP_STATS_M) ? K_ROWS_STATS : EP == EP_PROJECT ? K_ROWS_PROJECT : (EP == EP_LINESEARCH || EP == EP_LINESEARCH_M) ? K_ROWS_LINESEARCH : EP == EP_CROSS ? K_ROWS_CROSS : K_ROWS_ACCUM, st);
         hipLaunchKernelGGL((k_rows_fused<N, EP>), dim3((unsigned)grid), dim3(256), 0, st, a);
     }
     HIP_TRY(hipGetLastError());
@@ -930,6 +930,23 @@ int ptycho_cg_project_multi(ptycho_handle h, int src_slot, int dst_slot, const v
     PTY_DISPATCH(h->ge.ndet, (do_cg_rows<NN, EP_PROJECT>(h, a, st)));
 }
 
+int ptycho_cg_intensity_modes(ptycho_handle h, int nmodes, void* inten, const void* data, double* sums, void* stream) {
+    int rc = check_handle(h);
+    if (rc) return rc;
+    if (nmodes < 1 || nmodes > kMaxModes) return fail(PTYCHO_ERR_ARG, "nmodes must be in [1, 8]");
+    if (!inten && !sums) return fail(PTYCHO_ERR_ARG, "nothing to compute: inten and sums are both null");
+    if (sums && !data) return fail(PTYCHO_ERR_ARG, "null operand");
+    RowFusedArgs a{};
+    for (int k = 0; k < nmodes; ++k) {
+        if (!slot_ready(h, 2 * k)) return fail(PTYCHO_ERR_ARG, "work slot is empty");
+        a.sm[k] = h->work[2 * k];
+    }
+    a.nmodes = nmodes;
+    a.acc1 = (float*)inten; a.data = (const float*)data; a.sums = sums;
+    hipStream_t st = (hipStream_t)stream;
+    PTY_DISPATCH(h->ge.ndet, (do_cg_rows<NN, EP_STATS_M>(h, a, st)));
+}
+
 int ptycho_cg_linesearch_modes(ptycho_handle h, int mode0, int nmodes, const void* data, const void* inten,
                                const double* ab, double gamma0, int ncand, double* costs, void* stream) {
     int rc = check_handle(h);
@@ -949,32 +966,8 @@ int ptycho_cg_linesearch_modes(ptycho_handle h, int mode0, int nmodes, const voi
     PTY_DISPATCH(h->ge.ndet, (do_cg_rows<NN, EP_LINESEARCH_M>(h, a, st)));
 }
 
-int ptycho_cg_accum_intensity(ptycho_handle h, int slot, void* inten, int first, void* stream) {
-    int rc = check_handle(h);
-    if (rc) return rc;
-    if (!inten) return fail(PTYCHO_ERR_ARG, "null operand");
-    if (!slot_ready(h, slot)) return fail(PTYCHO_ERR_ARG, "work slot is empty");
-    RowFusedArgs a{};
-    a.s1 = h->work[slot]; a.acc1 = (float*)inten; a.first = first;
-    hipStream_t st = (hipStream_t)stream;
-    PTY_DISPATCH(h->ge.ndet, (do_cg_rows<NN, EP_ACCUM_I>(h, a, st)));
-}
 
 
-int ptycho_cg_array_stats(ptycho_handle h, const void* inten, const void* data, double* sums, void* stream) {
-    int rc = check_handle(h);
-    if (rc) return rc;
-    if (!inten || !data || !sums) return fail(PTYCHO_ERR_ARG, "null operand");
-    const long long n = (long long)h->ge.ptheta * h->ge.nscan * h->ge.ndet * h->ge.ndet;
-    hipStream_t st = (hipStream_t)stream;
-    {
-        ProfSpan ps(h, K_ARRAY_REDUCE, st);
-        hipLaunchKernelGGL(k_array_stats, dim3((unsigned)(h->n_cu * 8)), dim3(256), 0, st, (const float*)inten,
-                           (const float*)data, n, sums);
-    }
-    HIP_TRY(hipGetLastError());
-    return PTYCHO_OK;
-}
 
 
 int ptycho_fft2(ptycho_handle h, void* dst, const void* src, size_t nbatch, int dir, void* stream) {

@@ -17,8 +17,8 @@ SYMBOLS = ("ptycho_create", "ptycho_free", "ptycho_destroy", "ptycho_get",
            "ptycho_profile", "ptycho_profile_read",
            "ptycho_cg_fwd_cols", "ptycho_cg_stats", "ptycho_cg_project",
            "ptycho_cg_adj_cols", "ptycho_cg_linesearch",
-           "ptycho_cg_accum_intensity", "ptycho_cg_array_stats", "ptycho_cg_project_multi",
-           "ptycho_cg_linesearch_modes",
+           "ptycho_cg_project_multi",
+           "ptycho_cg_intensity_modes", "ptycho_cg_linesearch_modes",
            "ptycho_cg_cross", "ptycho_cg_argmax", "ptycho_cg_zoom",
            "ptycho_last_error", "ptycho_version")
 
@@ -53,9 +53,8 @@ cg_stats = _sig("ptycho_cg_stats", _i, _vp, _i, _vp, _vp, _vp)
 cg_project = _sig("ptycho_cg_project", _i, _vp, _i, _i, _vp, _vp, _vp, _vp)
 cg_adj_cols = _sig("ptycho_cg_adj_cols", _i, _vp, _i, _vp, _vp, _vp, _i, _vp)
 cg_linesearch = _sig("ptycho_cg_linesearch", _i, _vp, _i, _i, _vp, _vp, ctypes.c_double, _i, _vp, _vp)
-cg_accum_intensity = _sig("ptycho_cg_accum_intensity", _i, _vp, _i, _vp, _i, _vp)
-cg_array_stats = _sig("ptycho_cg_array_stats", _i, _vp, _vp, _vp, _vp, _vp)
 cg_project_multi = _sig("ptycho_cg_project_multi", _i, _vp, _i, _i, _vp, _vp, _vp, _i, _vp, _vp)
+cg_intensity_modes = _sig("ptycho_cg_intensity_modes", _i, _vp, _i, _vp, _vp, _vp, _vp)
 cg_linesearch_modes = _sig("ptycho_cg_linesearch_modes", _i, _vp, _i, _i, _vp, _vp, _vp, ctypes.c_double, _i, _vp, _vp)
 cg_cross = _sig("ptycho_cg_cross", _i, _vp, _i, _i, ctypes.c_double, _vp, _vp)
 cg_argmax = _sig("ptycho_cg_argmax", _i, _vp, _i, _vp, _vp)

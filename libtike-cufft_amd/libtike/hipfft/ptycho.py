@@ -737,9 +737,9 @@ class CGPtychoSolver(PtychoHIP):
         A = lambda k: 2 * k          # column pass of fwd(psi, probe_k)
         B = lambda k: 2 * k + 1      # residual of mode k, then column pass of fwd(direction, .)
 
-        def sum_intensity():
-            for k in range(M):
-                nat.check(nat.cg_accum_intensity(self._h, A(k), _ptr(inten), int(k == 0), _stream()))
+        def sum_intensity(stats=None):          # inten = sum_k |slot A(k)|^2 (+ a, b of :342-343) in one pass
+            nat.check(nat.cg_intensity_modes(self._h, M, _ptr(inten), _ptr(data),
+                                             _ptr(stats) if stats is not None else None, _stream()))
 
         dpsi = gradpsi0 = None
         dprb = gradprb0 = gradprb = None
@@ -751,9 +751,8 @@ class CGPtychoSolver(PtychoHIP):
             # 1) object step ------------------------------------------------------------
             for k in range(M):                                                  # :329-333
                 self._cg_fwd_cols(A(k), psi, scan, mode(probe, k))
-            sum_intensity()
             sums.zero_()
-            nat.check(nat.cg_array_stats(self._h, _ptr(inten), _ptr(data), _ptr(sums), _stream()))
+            sum_intensity(sums)
             self._allreduce(sums)
             ab32 = sums.to(torch.float32)
             probe *= (ab32[0] / ab32[1])                                        # :344
