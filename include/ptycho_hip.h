@@ -166,7 +166,7 @@ int ptycho_set_option(ptycho_handle h, const char* name, long long value);
  * the recorded launches, returns summed milliseconds and launch counts per kernel
  * (index 0 k_cols<FWD>, 1 k_rows<fwd>, 2 k_rows<inv>, 3 k_cols<ADJ_OBJ>,
  * 4 k_cols<ADJ_PRB>, 5 k_cols<PLAIN>, 6 position sort, 7-9 fused CG row passes,
- * 10 k_fwd_team, 11 accumulate row passes, 12 array reductions, 13 cross row pass,
+ * 10 k_fwd_team, 11-12 unused, 13 cross row pass,
  * 14 arg-max column pass, 15 zoomed DFT + arg-max; n >= 16)
  * and clears the record.
  * No counterpart in the reference (it has no timing code). */
