@@ -261,13 +261,14 @@ class PtychoHIP:
 
         The reference uploads, solves and downloads one partition at a time, fully
         synchronously.  Here the next partition's ``data / psi / scan / probe`` are staged
-        through pinned memory on a copy stream while the current partition is being solved
-        (angle streaming).  Angle partitions are independent problems, so a
+        through two reused sets of pinned buffers by a worker thread and copied on a copy
+        stream while the current partition is being solved (angle streaming).  Angle partitions are independent problems, so a
         multi-GPU job gives every rank its own partitions with no collective:
         ``angle_shard=(rank, world)`` restricts this call to partitions ``rank, rank+world, ...``
         (the other entries of the returned arrays keep their input values).
         """
         assert probe.ndim == 4, "probe needs 4 dimensions, not %d" % probe.ndim
+        import threading
         psi = psi.copy()
         probe = probe.copy()
         nparts = scan.shape[0] // self.ptheta
@@ -275,23 +276,43 @@ class PtychoHIP:
         mine = list(range(nparts))[rank::world]
         dev = self._device
         copy_stream = torch.cuda.Stream(device=dev)
+        arrays = (data, psi, scan, probe)
+        # two sets of pinned staging buffers, filled by a worker thread while the main thread
+        # drives the solver (the pinned copy of 1 GiB of data takes longer than its DMA)
+        pinned = [[torch.empty((self.ptheta,) + x.shape[1:], dtype=torch.from_numpy(x[:0]).dtype).pin_memory()
+                   for x in arrays] for _ in range(min(2, len(mine)))]
+        done = [None, None]                       # H2D-complete events of the two sets
 
-        def stage(k):
+        def stage(n, box):
+            k = mine[n]
             ids = slice(k * self.ptheta, (k + 1) * self.ptheta)
+            bufs = pinned[n % 2]
+            if done[n % 2] is not None:
+                done[n % 2].synchronize()         # the DMA out of this set (partition n-2) is over
+            for b, x in zip(bufs, arrays):
+                b.copy_(torch.from_numpy(np.ascontiguousarray(x[ids])))
             with torch.cuda.stream(copy_stream):
-                t = [torch.from_numpy(np.ascontiguousarray(x[ids])).pin_memory().to(dev, non_blocking=True)
-                     for x in (data, psi, scan, probe)]
+                t = [b.to(dev, non_blocking=True) for b in bufs]
                 ev = torch.cuda.Event()
                 ev.record(copy_stream)
-            return ids, t, ev
+            done[n % 2] = ev
+            box.append((ids, t, ev))
 
-        staged = stage(mine[0]) if mine else None
-        for n, k in enumerate(mine):
-            ids, (d_gpu, psi_gpu, scan_gpu, prb_gpu), ev = staged
+        def start(n):
+            box = []
+            th = threading.Thread(target=stage, args=(n, box), daemon=True)
+            th.start()
+            return th, box
+
+        pending = start(0) if mine else None
+        for n in range(len(mine)):
+            th, box = pending
+            th.join()
+            ids, (d_gpu, psi_gpu, scan_gpu, prb_gpu), ev = box[0]
             torch.cuda.current_stream().wait_event(ev)
             for t in (d_gpu, psi_gpu, scan_gpu, prb_gpu):
                 t.record_stream(torch.cuda.current_stream())
-            staged = stage(mine[n + 1]) if n + 1 < len(mine) else None
+            pending = start(n + 1) if n + 1 < len(mine) else None
             result = self.run(d_gpu, psi_gpu, scan_gpu, prb_gpu, **kwargs)
             psi[ids] = self.asnumpy(result["psi"])
             probe[ids] = self.asnumpy(result["probe"])
