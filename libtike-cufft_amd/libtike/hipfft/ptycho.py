@@ -236,7 +236,8 @@ class PtychoHIP:
         step = self.ptheta
         for ids in range(0, inputs[0].shape[0] - step + 1, step):
             dev = [xp.asarray(x[ids:ids + step]) for x in inputs]
-            output[ids:ids + step] = self.asnumpy(function(*dev))
+            # device -> final host memory in one copy (no intermediate host tensor)
+            torch.from_numpy(output[ids:ids + step]).copy_(function(*dev))
         return output
 
     def fwd_ptycho_batch(self, psi, scan, probe):
