@@ -16,7 +16,8 @@ roofline with the algorithmic bytes of BASELINE.md section 3 and reports live
 per-kernel durations (HIP events on the launch stream, taken inside the library);
 ``cpu_baseline`` times the NumPy/SciPy oracle on a bounded sample on this host's
 cores.  Secondary: ``cg_iterations_per_s`` (the reference CG loop on the same
-problem).
+problem, 50 iterations) and, for N > 1, ``cg_strong_iterations_per_s`` (the same 4096
+positions split over the ranks: strong scaling of the CG loop).
 """
 import argparse
 import json
