@@ -225,28 +225,33 @@ def main():
             dt = float(t.item())
         strong = None
         if dist and ngpu > 1 and R % ngpu == 0:
-            # strong scaling of the CG loop (BASELINE.json target: >= 6x at 8 GPUs): the SAME
-            # 4096-position problem of configs[1], raster rows [r R/N, (r+1) R/N) on rank r
-            del data
-            Rr = R // ngpu
-            nz1, n1 = syn.object_size_for(R, R, step, nprb)
-            psi1 = torch.as_tensor(syn.random_object(nz1, n1, np.random.default_rng(1234)), device=dev)
-            scan1 = torch.as_tensor(syn.raster_scan(Rr, R, step, np.random.default_rng(99 + rank),
-                                                     y0=float(rank * Rr * step)), device=dev)
-            s2 = pt.CGPtychoSolver(Rr * R, nprb, ndet, 1, nz1, n1, group=dist.group.WORLD)
-            s2.verbose = False
-            data1 = (torch.abs(s2.fwd(psi1, scan1, prb)) ** 2).contiguous()
-            s2.run(data1, torch.ones_like(psi1), scan1.clone(), prb[:, None].clone(), piter=2)
-            fence()
-            t0 = time.perf_counter()
-            s2.run(data1, torch.ones_like(psi1), scan1.clone(), prb[:, None].clone(), piter=args.cg_iters)
-            fence()
-            t = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            strong = {"cg_strong_iterations_per_s": args.cg_iters / float(t.item()),
-                      "cg_strong_config": "%d positions in total (%d per GPU), same loop" % (R * R, Rr * R)}
-            s2.free()
-            data = data1
+            try:
+                # strong scaling of the CG loop (BASELINE.json target: >= 6x at 8 GPUs): the SAME
+                # 4096-position problem of configs[1], raster rows [r R/N, (r+1) R/N) on rank r
+                del data
+                Rr = R // ngpu
+                nz1, n1 = syn.object_size_for(R, R, step, nprb)
+                psi1 = torch.as_tensor(syn.random_object(nz1, n1, np.random.default_rng(1234)), device=dev)
+                scan1 = torch.as_tensor(syn.raster_scan(Rr, R, step, np.random.default_rng(99 + rank),
+                                                         y0=float(rank * Rr * step)), device=dev)
+                s2 = pt.CGPtychoSolver(Rr * R, nprb, ndet, 1, nz1, n1, group=dist.group.WORLD)
+                s2.verbose = False
+                data1 = (torch.abs(s2.fwd(psi1, scan1, prb)) ** 2).contiguous()
+                s2.run(data1, torch.ones_like(psi1), scan1.clone(), prb[:, None].clone(), piter=2)
+                fence()
+                t0 = time.perf_counter()
+                s2.run(data1, torch.ones_like(psi1), scan1.clone(), prb[:, None].clone(), piter=args.cg_iters)
+                fence()
+                t = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                strong = {"cg_strong_iterations_per_s": args.cg_iters / float(t.item()),
+                          "cg_strong_config": "%d positions in total (%d per GPU), same loop" % (R * R, Rr * R)}
+                s2.free()
+                data = data1
+            except Exception as e:      # never let the secondary figure break the primary line
+                print("strong-scaling CG run failed: %r" % (e,), file=sys.stderr)
+                strong = None
+                data = None
         cg = {"cg_iterations_per_s": args.cg_iters / dt, "cg_iters_timed": args.cg_iters,
               "cg_ms_per_iteration": dt / args.cg_iters * 1e3,
               "cg_config": "gaussian, 1 mode, no probe recovery, position correction on (reference loop), "
