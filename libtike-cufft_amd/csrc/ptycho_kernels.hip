@@ -42,6 +42,7 @@ namespace {
 #include "k_rows.hpp"
 #include "k_cols_window.hpp"
 #include "k_team.hpp"
+#include "k_fwd_fused.hpp"
 #include "k_zoom.hpp"
 
 // ---------------------------------------------------------------------------
@@ -50,7 +51,7 @@ namespace {
 thread_local std::string g_err;
 
 // kernel ids for the in-library profiler (ptycho_profile_read)
-enum { K_COLS_FWD = 0, K_ROWS_FWD = 1, K_ROWS_INV = 2, K_COLS_ADJ_OBJ = 3, K_COLS_ADJ_PRB = 4, K_COLS_PLAIN = 5, K_SORT = 6, K_ROWS_STATS = 7, K_ROWS_PROJECT = 8, K_ROWS_LINESEARCH = 9, K_FWD_TEAM = 10, K_ROWS_ACCUM = 11, K_ARRAY_REDUCE = 12, K_ROWS_CROSS = 13, K_COLS_ARGMAX = 14, K_ZOOM = 15, K_COUNT = 16 };
+enum { K_COLS_FWD = 0, K_ROWS_FWD = 1, K_ROWS_INV = 2, K_COLS_ADJ_OBJ = 3, K_COLS_ADJ_PRB = 4, K_COLS_PLAIN = 5, K_SORT = 6, K_ROWS_STATS = 7, K_ROWS_PROJECT = 8, K_ROWS_LINESEARCH = 9, K_FWD_TEAM = 10, K_FWD_FUSED = 11, K_ARRAY_REDUCE = 12, K_ROWS_CROSS = 13, K_COLS_ARGMAX = 14, K_ZOOM = 15, K_COUNT = 16 };
 
 int fail(int code, const std::string& msg) {
     g_err = msg;
@@ -85,6 +86,8 @@ struct ptycho_handle_s {
     int use_team = 0;         // 1: forward operator as one persistent XCD-team launch (experimental)
     int use_split = 1;        // ndet = 256: one radix-16 step of the DFT over y runs in the row pass
     int use_pipeline = 0;     // 1: column and row passes of neighbouring chunks overlap on two streams (experimental)
+    int use_fused = 0;        // ndet = 256 forward as one launch (k_fwd_fused256): 0 off (default: measured slower), 1 / 2 class tiles per pass
+    c32* prbp = nullptr;      // fused forward: c * probe in a zero-bordered ndet x ndet frame, per angle
     int profile_serial = 0;   // 1: no pipelining (set while the in-library profiler times kernels one by one)
     hipStream_t aux = nullptr;               // second stream of the pipeline
     std::vector<hipEvent_t> evs;             // reusable events (no timing)
@@ -367,6 +370,32 @@ bool pipeline_applies(ptycho_handle h, long long total) {
 template <int N>
 int do_fwd_team(ptycho_handle h, c32* g, const c32* f, const float* scan, const c32* prb, hipStream_t st);
 
+int do_fwd_fused(ptycho_handle h, c32* g, const c32* f, const float* scan, const c32* prb, hipStream_t st) {
+    const Geom& ge = h->ge;
+    const int total = ge.ptheta * ge.nscan;
+    const int N = ge.ndet;
+    if (!h->prbp) HIP_TRY(hipMalloc((void**)&h->prbp, (size_t)ge.ptheta * N * N * sizeof(c32)));
+    // positions in sorted order: the workgroups in flight then touch neighbouring object rows (L2 hits)
+    int rc = sort_positions(h, scan, st);
+    if (rc) return rc;
+    const int npix = ge.ptheta * N * N;
+    hipLaunchKernelGGL(k_pad_probe, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, st, prb, h->prbp, ge);
+    FusedArgs fa{};
+    fa.f = f; fa.g = g; fa.prbp = h->prbp; fa.scan = scan; fa.table = h->table; fa.order = h->order; fa.ge = ge; fa.total = total;
+    static const int fused_dbg = std::getenv("PTYCHO_HIP_FUSED_DBG") ? std::atoi(std::getenv("PTYCHO_HIP_FUSED_DBG")) : 0;
+    fa.dbg = fused_dbg;
+    const int tiles = h->use_fused >= 2 ? 2 : 1;
+    const int nitems = total * (4 / tiles);
+    const int grid = nitems < h->n_cu ? nitems : h->n_cu;
+    {
+        ProfSpan ps(h, K_FWD_FUSED, st);
+        if (tiles == 2) hipLaunchKernelGGL((k_fwd_fused256<2>), dim3((unsigned)grid), dim3(1024), 0, st, fa);
+        else hipLaunchKernelGGL((k_fwd_fused256<1>), dim3((unsigned)grid), dim3(1024), 0, st, fa);
+    }
+    HIP_TRY(hipGetLastError());
+    return PTYCHO_OK;
+}
+
 template <int N>
 int do_fwd(ptycho_handle h, c32* g, const c32* f, const float* scan, const c32* prb, hipStream_t st) {
     constexpr int C = ColCfg<N>::C;
@@ -378,6 +407,8 @@ int do_fwd(ptycho_handle h, c32* g, const c32* f, const float* scan, const c32* 
     int rc = PTYCHO_OK;
     if constexpr (N == 256) {
         if (h->use_team && window) return do_fwd_team<N>(h, g, f, scan, prb, st);
+        // single launch, no intermediate in HBM; needs 16-byte aligned object rows
+        if (h->use_fused && ge.n % 2 == 0 && ((size_t)f % 16) == 0) return do_fwd_fused(h, g, f, scan, prb, st);
     }
     if constexpr (WinCfg<N>::fits) {
         if (pipeline_applies(h, total)) return do_fwd_pipelined<N>(h, g, f, scan, prb, st);
@@ -611,7 +642,7 @@ int do_cg_rows(ptycho_handle h, RowFusedArgs a, hipStream_t st) {
     long long nb = (a.nrows + B - 1) / B;
     long long grid = nb < (long long)h->n_cu * 8 ? nb : (long long)h->n_cu * 8;
     {
-        ProfSpan ps(h, (EP == EP_STATS || EP == EP_STATS_M) ? K_ROWS_STATS : EP == EP_PROJECT ? K_ROWS_PROJECT : (EP == EP_LINESEARCH || EP == EP_LINESEARCH_M) ? K_ROWS_LINESEARCH : EP == EP_CROSS ? K_ROWS_CROSS : K_ROWS_ACCUM, st);
+        ProfSpan ps(h, (EP == EP_STATS || EP == EP_STATS_M) ? K_ROWS_STATS : EP == EP_PROJECT ? K_ROWS_PROJECT : (EP == EP_LINESEARCH || EP == EP_LINESEARCH_M) ? K_ROWS_LINESEARCH : K_ROWS_CROSS, st);
         hipLaunchKernelGGL((k_rows_fused<N, EP>), dim3((unsigned)grid), dim3(256), 0, st, a);
     }
     HIP_TRY(hipGetLastError());
@@ -668,8 +699,8 @@ int alloc_sort(ptycho_handle h) {
 }
 
 void release(ptycho_handle h) {
-    void* ptrs[] = {h->table, h->scratch, h->keys_a, h->keys_b, h->vals_a, h->order, h->sort_tmp, h->ring, h->ctrl, h->zoom_phase};
-    h->ring = nullptr; h->ctrl = nullptr; h->zoom_phase = nullptr;
+    void* ptrs[] = {h->table, h->scratch, h->keys_a, h->keys_b, h->vals_a, h->order, h->sort_tmp, h->ring, h->ctrl, h->zoom_phase, h->prbp};
+    h->ring = nullptr; h->ctrl = nullptr; h->zoom_phase = nullptr; h->prbp = nullptr;
     for (auto& w : h->work) { if (w) (void)hipFree(w); w = nullptr; }
     for (void* q : ptrs)
         if (q) (void)hipFree(q);
@@ -729,6 +760,8 @@ int ptycho_create(ptycho_handle* out, size_t ptheta, size_t nz, size_t n, size_t
     if (env) h->use_pipeline = std::atoi(env) != 0;
     env = std::getenv("PTYCHO_HIP_TEAM");
     if (env) h->use_team = std::atoi(env) != 0;
+    env = std::getenv("PTYCHO_HIP_FUSED");
+    if (env) h->use_fused = std::atoi(env);
     h->chunk = default_chunk(h->ge);
     int rc = alloc_scratch(h);
     if (!rc) rc = alloc_sort(h);
@@ -807,6 +840,10 @@ int ptycho_set_option(ptycho_handle h, const char* name, long long value) {
     }
     if (std::strcmp(name, "team") == 0) {
         h->use_team = value != 0;
+        return PTYCHO_OK;
+    }
+    if (std::strcmp(name, "fused") == 0) {
+        h->use_fused = (int)value;
         return PTYCHO_OK;
     }
     return fail(PTYCHO_ERR_ARG, std::string("unknown option ") + name);

@@ -65,7 +65,7 @@ profile_read = _sig("ptycho_profile_read", _i, _vp, ctypes.POINTER(ctypes.c_doub
 KERNEL_NAMES = ("k_cols<FWD>", "k_rows<fwd>", "k_rows<inv>", "k_cols<ADJ_OBJ>",
                 "k_cols<ADJ_PRB>", "k_cols<PLAIN>", "sort_positions",
                 "k_rows_fused<STATS>", "k_rows_fused<PROJECT>", "k_rows_fused<LINESEARCH>",
-                "k_fwd_team", "unused11", "unused12",
+                "k_fwd_team", "k_fwd_fused256", "unused12",
                 "k_rows_fused<CROSS>", "k_cols_argmax", "k_zoom_argmax")
 last_error = _sig("ptycho_last_error", ctypes.c_char_p)
 version = _sig("ptycho_version", ctypes.c_char_p)
