@@ -150,14 +150,11 @@ int ptycho_cg_zoom(ptycho_handle h, const void* image_product, const void* best,
  * same pointer with unchanged contents as in the previous call, so the position sort is
  * reused; set 0 after modifying scan; default 0);
  * "split" (ndet = 256: 1 = one radix-16 step of the DFT over y runs in the row pass [default]);
- * "pipeline" (1 = chunked two-stream overlap of column and row passes; experimental, default 0);
- * "team" (1 = forward operator as one persistent launch of per-XCD teams that keep the
- * column->row intermediate in L2; experimental, default 0).  ptycho_get(h, 102) returns
- * the abort word of the last team launch (non-zero = a bounded spin timed out).
+ * "fused" (ndet = 256: forward operator as ONE launch that keeps the column<->row intermediate on
+ * the CU, k_fwd_fused256: 0 = off, 1 / 2 = one / two class tiles per pass).
  * Environment variables read at handle creation / first launch, for experiments only:
- * PTYCHO_HIP_CHUNK, PTYCHO_HIP_WINDOW, PTYCHO_HIP_SPLIT, PTYCHO_HIP_PIPELINE, PTYCHO_HIP_TEAM
- * (initial values of the options above), PTYCHO_HIP_NT (nontemporal load/store mask),
- * PTYCHO_HIP_ROWGRID, PTYCHO_HIP_COLSEGS, PTYCHO_HIP_PIPE_CHUNKS, PTYCHO_HIP_PIPE_WGS (launch
+ * PTYCHO_HIP_CHUNK, PTYCHO_HIP_WINDOW, PTYCHO_HIP_SPLIT, PTYCHO_HIP_FUSED (initial values of the
+ * options above), PTYCHO_HIP_NT (nontemporal load/store mask), PTYCHO_HIP_ROWGRID, PTYCHO_HIP_COLSEGS (launch
  * geometry), PTYCHO_HIP_ZOOM_SCALAR (zoomed DFT without the matrix cores). */
 int ptycho_set_option(ptycho_handle h, const char* name, long long value);
 

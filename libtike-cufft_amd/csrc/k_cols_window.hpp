@@ -566,22 +566,61 @@ __global__ __launch_bounds__(ColCfg<N>::NT) void k_cols_gatherwin(const ColArgs 
     if (MODE == M_ADJ_PRB && cur_t >= 0) flush_probe(cur_t);
 }
 
-// sort key of one position: angle | column bucket | row; skipped positions last
-__global__ void k_sort_keys(const float* __restrict__ scan, const Geom ge, const int total,
-                            unsigned long long* __restrict__ keys, int* __restrict__ vals) {
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= total) return;
+// ---------------------------------------------------------------------------
+// Processing order of the positions: sorted by (angle, column bucket, row), skipped positions last.
+// One launch, no library: every position is RANKED by counting the keys below it (ties broken by
+// index, so the ranks are a permutation and the order is deterministic).  Workgroup (iblock, slice)
+// counts, for its 256 positions, the smaller keys among the tiles {slice, slice + nslices, ...}; the
+// partial counts meet in counts[] (integer atomics) and the last slice of an iblock to arrive writes
+// order[rank] = position and clears the counters for the next call.  n^2 / 2 key compares: 1 us of
+// work spread over the chip at 4096 positions, ~0.1 ms at the 32768 positions of a configs[3] shard
+// (the radix sort it replaces took 30-60 us in several launches at 4096).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ unsigned long long sort_key(const float* __restrict__ scan, const Geom& ge, const int p) {
     const Pos q = decode_pos(scan, p, ge);
-    unsigned long long key = ~0ull;
-    if (q.valid) {
-        const unsigned long long t = (unsigned long long)(p / ge.nscan);
-        unsigned long long bx = (unsigned long long)(q.sx / kBucketPx), sy = (unsigned long long)q.sy;
-        if (bx > 0x3fffffull) bx = 0x3fffffull;
-        if (sy > 0x3fffffull) sy = 0x3fffffull;
-        key = (t << 44) | (bx << 22) | sy;
+    if (!q.valid) return ~0ull;
+    const unsigned long long t = (unsigned long long)(p / ge.nscan);
+    unsigned long long bx = (unsigned long long)(q.sx / kBucketPx), sy = (unsigned long long)q.sy;
+    if (bx > 0x3fffffull) bx = 0x3fffffull;
+    if (sy > 0x3fffffull) sy = 0x3fffffull;
+    return (t << 44) | (bx << 22) | sy;
+}
+
+__global__ __launch_bounds__(256) void k_rank_positions(const float* __restrict__ scan, const Geom ge, const int total,
+                                                        const int nslices, int* __restrict__ counts,
+                                                        int* __restrict__ tickets, int* __restrict__ order) {
+    __shared__ unsigned long long keys[256];
+    __shared__ int last;
+    const int tid = threadIdx.x;
+    const int iblock = blockIdx.x / nslices, slice = blockIdx.x % nslices;
+    const int i = iblock * 256 + tid;
+    const unsigned long long ki = i < total ? sort_key(scan, ge, i) : ~0ull;
+    const int ntiles = (total + 255) / 256;
+    int cnt = 0;
+    for (int tile = slice; tile < ntiles; tile += nslices) {
+        const int jl = tile * 256 + tid;
+        __syncthreads();
+        keys[tid] = jl < total ? sort_key(scan, ge, jl) : ~0ull;
+        __syncthreads();
+        const int j0 = tile * 256;
+#pragma unroll 8
+        for (int jj = 0; jj < 256; ++jj) {
+            const unsigned long long kj = keys[jj];
+            cnt += (kj < ki || (kj == ki && j0 + jj < i)) ? 1 : 0;   // j >= total: key ~0 and j > i, never counted
+        }
     }
-    keys[p] = key;
-    vals[p] = p;
+    if (i < total && cnt) atomicAdd(counts + i, cnt);
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) last = atomicAdd(tickets + iblock, 1) == nslices - 1;
+    __syncthreads();
+    if (!last) return;
+    __threadfence();
+    if (i < total) {
+        const int rank = atomicExch(counts + i, 0);   // read the total and clear it for the next call
+        order[rank] = i;
+    }
+    if (tid == 0) tickets[iblock] = 0;
 }
 
 // Column pass of the coarse cross-correlation with a fused arg-max (ptycho.py:204-207):

@@ -36,7 +36,6 @@ struct FusedArgs {
     const int* order;   // processing order (nullptr: identity)
     Geom ge;
     int total;          // positions
-    int dbg;            // timing experiments (wrong results): 1 no staging after chunk 0, 2 no probe loads, 4 no column / row phases
 };
 
 // c * prb in a zero-bordered 256 x 256 frame (kernels.cu:48-65: centred pad, c = 1/ndet)
@@ -179,8 +178,8 @@ __global__ __launch_bounds__(1024) void k_fwd_fused256(const FusedArgs a) {
 #pragma unroll
             for (int b = 0; b < 2; ++b) {
                 c32 prn[4] = {zero, zero, zero, zero};
-                if ((c < 7 || b == 0) && !(a.dbg & 2)) probe_load(prn, b == 0 ? c : c + 1, b == 0 ? 1 : 0);
-                if (c < 7 && !(a.dbg & 1)) stage_load(c + 1, b);
+                if (c < 7 || b == 0) probe_load(prn, b == 0 ? c : c + 1, b == 0 ? 1 : 0);
+                if (c < 7) stage_load(c + 1, b);
                 c32 qv[4];
 #pragma unroll
                 for (int n1 = 0; n1 < 4; ++n1) {
@@ -207,7 +206,7 @@ __global__ __launch_bounds__(1024) void k_fwd_fused256(const FusedArgs a) {
                         vb[b * 8 + c] = cmul(s + mul_pi(d), wtab[(3 * n2) & (N - 1)]);
                     }
                 }
-                if (c < 7 && !(a.dbg & 1)) stage_store((c + 1) & 1, b);
+                if (c < 7) stage_store((c + 1) & 1, b);
 #pragma unroll
                 for (int n1 = 0; n1 < 4; ++n1) prh[n1] = prn[n1];
             }
@@ -250,10 +249,6 @@ __global__ __launch_bounds__(1024) void k_fwd_fused256(const FusedArgs a) {
             frw.template store<1>(v, j0r, [&](int i, c32 val) { __builtin_nontemporal_store(val, drow + i); });
         };
 
-        if (a.dbg & 4) {
-            if (va[0].x == 123.456f) gt[tid] = va[3] + (TILES == 2 ? vb[5] : va[7]);
-            continue;
-        }
         col_fft(va);
         if (TILES == 2) col_fft(vb);
         tile_store(va);

@@ -15,13 +15,12 @@
 //   adj : k_rows       inverse DFT over x, g -> chunk scratch (g untouched)
 //         k_cols<ADJ>  inverse DFT over y -> conj(probe) / conj(patch) -> f / prb
 //
-// Work is issued in chunks of scan positions so that the intermediate of a
-// chunk is still resident in the 256 MiB Infinity Cache when the second pass
-// reads it.
+// The adjoint's intermediate lives in a scratch of at most 4 GiB (one launch pair per chunk of
+// positions; at 4096 x 256^2 that is a single pair).  For ndet = 256 one radix-16 step of the DFT over
+// y moves into the row pass ("split"); k_fwd_fused.hpp holds the single-launch forward.
 #include <hip/hip_runtime.h>
 
 #include <cstring>
-#include <rocprim/device/device_radix_sort.hpp>
 
 #include <cmath>
 #include <cstdio>
@@ -41,7 +40,6 @@ namespace {
 #include "k_cols_plain.hpp"
 #include "k_rows.hpp"
 #include "k_cols_window.hpp"
-#include "k_team.hpp"
 #include "k_fwd_fused.hpp"
 #include "k_zoom.hpp"
 
@@ -51,7 +49,7 @@ namespace {
 thread_local std::string g_err;
 
 // kernel ids for the in-library profiler (ptycho_profile_read)
-enum { K_COLS_FWD = 0, K_ROWS_FWD = 1, K_ROWS_INV = 2, K_COLS_ADJ_OBJ = 3, K_COLS_ADJ_PRB = 4, K_COLS_PLAIN = 5, K_SORT = 6, K_ROWS_STATS = 7, K_ROWS_PROJECT = 8, K_ROWS_LINESEARCH = 9, K_FWD_TEAM = 10, K_FWD_FUSED = 11, K_ARRAY_REDUCE = 12, K_ROWS_CROSS = 13, K_COLS_ARGMAX = 14, K_ZOOM = 15, K_COUNT = 16 };
+enum { K_COLS_FWD = 0, K_ROWS_FWD = 1, K_ROWS_INV = 2, K_COLS_ADJ_OBJ = 3, K_COLS_ADJ_PRB = 4, K_COLS_PLAIN = 5, K_SORT = 6, K_ROWS_STATS = 7, K_ROWS_PROJECT = 8, K_ROWS_LINESEARCH = 9, K_CG_SCALARS = 10, K_FWD_FUSED = 11, K_CG_UPDATE = 12, K_ROWS_CROSS = 13, K_COLS_ARGMAX = 14, K_ZOOM = 15, K_COUNT = 16 };
 
 int fail(int code, const std::string& msg) {
     g_err = msg;
@@ -73,29 +71,17 @@ struct ptycho_handle_s {
     c32* scratch = nullptr;   // chunk * ndet^2 complex64
     long long chunk = 0;      // positions per launch pair
     // position sort (object / probe adjoint)
-    unsigned long long* keys_a = nullptr;
-    unsigned long long* keys_b = nullptr;
-    int* vals_a = nullptr;
-    int* order = nullptr;
-    void* sort_tmp = nullptr;
-    size_t sort_tmp_bytes = 0;
+    int* order = nullptr;          // processing order: position order[k] is the k-th in (angle, column bucket, row) order
+    int* sort_counts = nullptr;    // k_rank_positions: partial ranks [positions] + tickets [ceil(positions / 256)], self-clearing
     static constexpr int kSlots = 2 * kMaxModes;
     c32* work[kSlots] = {};   // CG work buffers (column-pass intermediates), all positions; 0/1 + per-mode pairs
     void* zoom_phase = nullptr;           // registration: per-pattern phases + whole-pixel shifts
     int use_window = 1;       // 0: direct-atomics object adjoint (k_cols<ADJ_OBJ>)
-    int use_team = 0;         // 1: forward operator as one persistent XCD-team launch (experimental)
     int use_split = 1;        // ndet = 256: one radix-16 step of the DFT over y runs in the row pass
-    int use_pipeline = 0;     // 1: column and row passes of neighbouring chunks overlap on two streams (experimental)
     int use_fused = 0;        // ndet = 256 forward as one launch (k_fwd_fused256): 0 off (default: measured slower), 1 / 2 class tiles per pass
     c32* prbp = nullptr;      // fused forward: c * probe in a zero-bordered ndet x ndet frame, per angle
-    int profile_serial = 0;   // 1: no pipelining (set while the in-library profiler times kernels one by one)
-    hipStream_t aux = nullptr;               // second stream of the pipeline
-    std::vector<hipEvent_t> evs;             // reusable events (no timing)
     int trust_order = 0;      // 1: caller vouches that scan is unchanged since the last sort
     const float* order_scan = nullptr;   // scan pointer the current order was computed from
-    c32* ring = nullptr;      // team ring: 8 XCD x 2 x Q tiles
-    unsigned* ctrl = nullptr; // team control words
-    int team_R = 0, team_Q = 0;
     int device = 0;
     int n_cu = 256;
     bool freed = false;
@@ -263,113 +249,6 @@ void strip_range(const Geom& ge, int& strip0, int& nstrips) {
 }
 
 
-// ---- two-stream pipeline -----------------------------------------------------------------
-// The column pass is latency/VALU bound and the row pass HBM bound, so running them one after
-// the other leaves either the memory system or the ALUs idle.  Work is cut into chunks of the
-// sorted order; the column pass of a chunk is launched with about one workgroup per CU, which
-// leaves LDS and wave slots for the row pass of the neighbouring chunk on a second stream
-// (a single column/row pair overlaps to ~0.87 of its summed time).  The caller's stream is
-// joined before returning, so the call is still stream ordered from the outside.
-// Measured at 4096 x 256^2: 3.13-3.66 ms per fwd+adj pair for 2-16 chunks and 256/512 column
-// workgroups against 2.91 ms un-pipelined -- shorter runs, one workgroup per CU and 16+ extra
-// launches cost more than the overlap returns.  Off by default (option "pipeline").
-int pipeline_ready(ptycho_handle h, size_t nev) {
-    if (!h->aux) HIP_TRY(hipStreamCreateWithFlags(&h->aux, hipStreamNonBlocking));
-    while (h->evs.size() < nev) {
-        hipEvent_t e;
-        HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        h->evs.push_back(e);
-    }
-    return PTYCHO_OK;
-}
-
-constexpr int kPipeChunksMax = 32;
-static int pipe_chunks() { static const int v = std::getenv("PTYCHO_HIP_PIPE_CHUNKS") ? std::atoi(std::getenv("PTYCHO_HIP_PIPE_CHUNKS")) : 8; return v < 2 ? 2 : (v > kPipeChunksMax ? kPipeChunksMax : v); }
-static int pipe_wgs(int n_cu) { static const int v = std::getenv("PTYCHO_HIP_PIPE_WGS") ? std::atoi(std::getenv("PTYCHO_HIP_PIPE_WGS")) : 0; return v > 0 ? v : n_cu; }
-
-template <int N>
-int do_fwd_pipelined(ptycho_handle h, c32* g, const c32* f, const float* scan, const c32* prb, hipStream_t st) {
-    constexpr int C = ColCfg<N>::C;
-    const Geom& ge = h->ge;
-    const int total = ge.ptheta * ge.nscan;
-    int strip0, nstrips;
-    strip_range<N>(ge, strip0, nstrips);
-    int rc = sort_positions(h, scan, st);
-    if (rc) return rc;
-    const int kPipeChunks = pipe_chunks();
-    rc = pipeline_ready(h, kPipeChunks + 1);
-    if (rc) return rc;
-    const int per = (total + kPipeChunks - 1) / kPipeChunks;
-    for (int c = 0; c < kPipeChunks; ++c) {
-        const int k0 = c * per, k1 = k0 + per < total ? k0 + per : total;
-        if (k0 >= k1) break;
-        ColArgs ca{};
-        ca.src = f; ca.dst = g; ca.aux = prb; ca.scan = scan; ca.table = h->table; ca.ge = ge;
-        ca.order = h->order; ca.k_begin = k0; ca.k_end = k1; ca.strip0 = strip0; ca.nstrips = nstrips;
-        if constexpr (WinCfg<N>::fits) rc = launch_gatherwin<N, M_FWD>(h, ca, st, pipe_wgs(h->n_cu));
-        if (rc) return rc;
-        HIP_TRY(hipEventRecord(h->evs[c], st));
-        HIP_TRY(hipStreamWaitEvent(h->aux, h->evs[c], 0));
-        RowArgs ra{};
-        ra.src = g; ra.dst = g; ra.table = h->table; ra.tile_index = h->order + k0; ra.dst_indexed = 1;
-        ra.nrows = (long long)(k1 - k0) * N; ra.xa = strip0 * C; ra.xb = (strip0 + nstrips) * C; ra.wa = 0; ra.wb = N;
-        rc = launch_rows<N, -1>(h, ra, h->aux);
-        if (rc) return rc;
-    }
-    HIP_TRY(hipEventRecord(h->evs[kPipeChunks], h->aux));
-    HIP_TRY(hipStreamWaitEvent(st, h->evs[kPipeChunks], 0));
-    return PTYCHO_OK;
-}
-
-template <int N>
-int do_adj_pipelined(ptycho_handle h, c32* f, const c32* g, const float* scan, c32* prb, int flg, hipStream_t st) {
-    constexpr int C = ColCfg<N>::C;
-    const Geom& ge = h->ge;
-    const int total = ge.ptheta * ge.nscan;
-    int strip0, nstrips;
-    strip_range<N>(ge, strip0, nstrips);
-    int rc = sort_positions(h, scan, st);
-    if (rc) return rc;
-    const int kPipeChunks = pipe_chunks();
-    rc = pipeline_ready(h, kPipeChunks + 2);
-    if (rc) return rc;
-    // the row passes run on the second stream; they must see the caller's inputs and the sort
-    HIP_TRY(hipEventRecord(h->evs[kPipeChunks + 1], st));
-    HIP_TRY(hipStreamWaitEvent(h->aux, h->evs[kPipeChunks + 1], 0));
-    const int per = (total + kPipeChunks - 1) / kPipeChunks;
-    for (int c = 0; c < kPipeChunks; ++c) {
-        const int k0 = c * per, k1 = k0 + per < total ? k0 + per : total;
-        if (k0 >= k1) break;
-        RowArgs ra{};
-        ra.src = g; ra.dst = h->scratch + (size_t)k0 * N * N; ra.table = h->table; ra.tile_index = h->order + k0;
-        ra.nrows = (long long)(k1 - k0) * N; ra.xa = 0; ra.xb = N; ra.wa = strip0 * C; ra.wb = (strip0 + nstrips) * C;
-        rc = launch_rows<N, +1>(h, ra, h->aux);
-        if (rc) return rc;
-        HIP_TRY(hipEventRecord(h->evs[c], h->aux));
-        HIP_TRY(hipStreamWaitEvent(st, h->evs[c], 0));
-        ColArgs ca{};
-        ca.src = h->scratch + (size_t)k0 * N * N; ca.scan = scan; ca.table = h->table; ca.ge = ge;
-        ca.order = h->order; ca.k_begin = k0; ca.k_end = k1; ca.strip0 = strip0; ca.nstrips = nstrips;
-        if (flg == 0) {
-            ca.dst = f; ca.aux = prb;
-            if constexpr (WinCfg<N>::fits) rc = launch_adjwin<N>(h, ca, st, pipe_wgs(h->n_cu));
-        } else {
-            ca.dst = prb; ca.aux = f;
-            if constexpr (WinCfg<N>::fits) rc = launch_gatherwin<N, M_ADJ_PRB>(h, ca, st, pipe_wgs(h->n_cu));
-        }
-        if (rc) return rc;
-    }
-    return PTYCHO_OK;
-}
-
-bool pipeline_applies(ptycho_handle h, long long total) {
-    // enough positions for 8 chunks of >= 16 runs each, the whole farplane fits the scratch
-    return h->use_pipeline && h->use_window && total >= 2048 && total <= h->chunk && !h->profile_serial;
-}
-
-template <int N>
-int do_fwd_team(ptycho_handle h, c32* g, const c32* f, const float* scan, const c32* prb, hipStream_t st);
-
 int do_fwd_fused(ptycho_handle h, c32* g, const c32* f, const float* scan, const c32* prb, hipStream_t st) {
     const Geom& ge = h->ge;
     const int total = ge.ptheta * ge.nscan;
@@ -382,8 +261,6 @@ int do_fwd_fused(ptycho_handle h, c32* g, const c32* f, const float* scan, const
     hipLaunchKernelGGL(k_pad_probe, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, st, prb, h->prbp, ge);
     FusedArgs fa{};
     fa.f = f; fa.g = g; fa.prbp = h->prbp; fa.scan = scan; fa.table = h->table; fa.order = h->order; fa.ge = ge; fa.total = total;
-    static const int fused_dbg = std::getenv("PTYCHO_HIP_FUSED_DBG") ? std::atoi(std::getenv("PTYCHO_HIP_FUSED_DBG")) : 0;
-    fa.dbg = fused_dbg;
     const int tiles = h->use_fused >= 2 ? 2 : 1;
     const int nitems = total * (4 / tiles);
     const int grid = nitems < h->n_cu ? nitems : h->n_cu;
@@ -406,12 +283,8 @@ int do_fwd(ptycho_handle h, c32* g, const c32* f, const float* scan, const c32* 
     const bool window = h->use_window && WinCfg<N>::fits;
     int rc = PTYCHO_OK;
     if constexpr (N == 256) {
-        if (h->use_team && window) return do_fwd_team<N>(h, g, f, scan, prb, st);
         // single launch, no intermediate in HBM; needs 16-byte aligned object rows
         if (h->use_fused && ge.n % 2 == 0 && ((size_t)f % 16) == 0) return do_fwd_fused(h, g, f, scan, prb, st);
-    }
-    if constexpr (WinCfg<N>::fits) {
-        if (pipeline_applies(h, total)) return do_fwd_pipelined<N>(h, g, f, scan, prb, st);
     }
     if (window) {
         rc = sort_positions(h, scan, st);
@@ -446,49 +319,12 @@ int do_fwd(ptycho_handle h, c32* g, const c32* f, const float* scan, const c32* 
 
 
 template <int N>
-int do_fwd_team(ptycho_handle h, c32* g, const c32* f, const float* scan, const c32* prb, hipStream_t st) {
-    constexpr int C = ColCfg<N>::C;
-    const Geom& ge = h->ge;
-    const int total = ge.ptheta * ge.nscan;
-    int strip0, nstrips;
-    strip_range<N>(ge, strip0, nstrips);
-    const size_t tile = (size_t)N * N * sizeof(c32);
-    int Q = (int)((1u << 20) / tile);   // about 1 MiB of tiles per ring buffer
-    if (Q < 1) Q = 1;
-    const int per = (total + 7) / 8;
-    const int R = (per + Q - 1) / Q + 1;
-    if (!h->ring || h->team_Q != Q || h->team_R < R) {
-        if (h->ring) { HIP_TRY(hipFree(h->ring)); h->ring = nullptr; }
-        if (h->ctrl) { HIP_TRY(hipFree(h->ctrl)); h->ctrl = nullptr; }
-        HIP_TRY(hipMalloc((void**)&h->ring, (size_t)8 * 2 * Q * tile));
-        HIP_TRY(hipMalloc((void**)&h->ctrl, (size_t)(16 + 8 * 2 * R) * sizeof(unsigned)));
-        h->team_Q = Q; h->team_R = R;
-    }
-    int rc = sort_positions(h, scan, st);
-    if (rc) return rc;
-    HIP_TRY(hipMemsetAsync(h->ctrl, 0, (size_t)(16 + 8 * 2 * h->team_R) * sizeof(unsigned), st));
-    TeamArgs ta{};
-    ta.f = f; ta.g = g; ta.prb = prb; ta.scan = scan; ta.table = h->table; ta.ge = ge;
-    ta.order = h->order; ta.total = total; ta.ring = h->ring; ta.ctrl = h->ctrl; ta.R = h->team_R; ta.Q = Q;
-    ta.strip0 = strip0; ta.nstrips = nstrips; ta.xa = strip0 * C; ta.xb = (strip0 + nstrips) * C;
-    {
-        ProfSpan ps(h, K_FWD_TEAM, st);
-        hipLaunchKernelGGL((k_fwd_team<N>), dim3((unsigned)(h->n_cu * 2)), dim3(256), 0, st, ta);
-    }
-    HIP_TRY(hipGetLastError());
-    return PTYCHO_OK;
-}
-
-template <int N>
 int do_adj(ptycho_handle h, c32* f, const c32* g, const float* scan, c32* prb, int flg, hipStream_t st) {
     constexpr int C = ColCfg<N>::C;
     const Geom& ge = h->ge;
     const long long total = (long long)ge.ptheta * ge.nscan;
     int strip0, nstrips;
     strip_range<N>(ge, strip0, nstrips);
-    if constexpr (WinCfg<N>::fits) {
-        if (pipeline_applies(h, total)) return do_adj_pipelined<N>(h, f, g, scan, prb, flg, st);
-    }
     const bool window = flg == 0 && h->use_window && WinCfg<N>::fits;
     // positions are visited in sorted order (angle, column bucket, row): neighbours in the
     // object are neighbours in time, which is what the LDS overlap-add window needs
@@ -674,43 +510,37 @@ int sort_positions(ptycho_handle h, const float* scan, hipStream_t st) {
     // changed since the previous call on this handle (option "trust_order") skips the sort.
     if (h->trust_order && h->order_scan == scan) return PTYCHO_OK;
     h->order_scan = scan;
-    ProfSpan ps(h, K_SORT, st);
-    hipLaunchKernelGGL(k_sort_keys, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, scan, h->ge, total,
-                       h->keys_a, h->vals_a);
+    const int iblocks = (total + 255) / 256;
+    int nslices = (2 * h->n_cu + iblocks - 1) / iblocks;
+    if (nslices > iblocks) nslices = iblocks;   // = number of key tiles
+    if (nslices < 1) nslices = 1;
+    {
+        ProfSpan ps(h, K_SORT, st);
+        hipLaunchKernelGGL(k_rank_positions, dim3((unsigned)(iblocks * nslices)), dim3(256), 0, st, scan, h->ge, total, nslices,
+                           h->sort_counts, h->sort_counts + total, h->order);
+    }
     HIP_TRY(hipGetLastError());
-    size_t bytes = h->sort_tmp_bytes;
-    HIP_TRY(rocprim::radix_sort_pairs(h->sort_tmp, bytes, h->keys_a, h->keys_b, h->vals_a, h->order,
-                                      (size_t)total, 0u, 64u, st));
     return PTYCHO_OK;
 }
 
 int alloc_sort(ptycho_handle h) {
     const size_t total = (size_t)h->ge.ptheta * h->ge.nscan;
-    HIP_TRY(hipMalloc((void**)&h->keys_a, total * sizeof(unsigned long long)));
-    HIP_TRY(hipMalloc((void**)&h->keys_b, total * sizeof(unsigned long long)));
-    HIP_TRY(hipMalloc((void**)&h->vals_a, total * sizeof(int)));
+    const size_t nwords = total + (total + 255) / 256;
     HIP_TRY(hipMalloc((void**)&h->order, total * sizeof(int)));
-    size_t bytes = 0;
-    HIP_TRY(rocprim::radix_sort_pairs(nullptr, bytes, h->keys_a, h->keys_b, h->vals_a, h->order, total, 0u, 64u,
-                                      (hipStream_t)0));
-    h->sort_tmp_bytes = bytes ? bytes : 16;
-    HIP_TRY(hipMalloc(&h->sort_tmp, h->sort_tmp_bytes));
+    HIP_TRY(hipMalloc((void**)&h->sort_counts, nwords * sizeof(int)));
+    HIP_TRY(hipMemset(h->sort_counts, 0, nwords * sizeof(int)));
     return PTYCHO_OK;
 }
 
 void release(ptycho_handle h) {
-    void* ptrs[] = {h->table, h->scratch, h->keys_a, h->keys_b, h->vals_a, h->order, h->sort_tmp, h->ring, h->ctrl, h->zoom_phase, h->prbp};
-    h->ring = nullptr; h->ctrl = nullptr; h->zoom_phase = nullptr; h->prbp = nullptr;
+    void* ptrs[] = {h->table, h->scratch, h->order, h->sort_counts, h->zoom_phase, h->prbp};
+    h->zoom_phase = nullptr; h->prbp = nullptr;
     for (auto& w : h->work) { if (w) (void)hipFree(w); w = nullptr; }
     for (void* q : ptrs)
         if (q) (void)hipFree(q);
-    h->table = nullptr; h->scratch = nullptr; h->keys_a = nullptr; h->keys_b = nullptr;
-    h->vals_a = nullptr; h->order = nullptr; h->sort_tmp = nullptr;
+    h->table = nullptr; h->scratch = nullptr; h->order = nullptr; h->sort_counts = nullptr;
     for (auto& sp : h->spans) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
     h->spans.clear();
-    for (auto& e : h->evs) (void)hipEventDestroy(e);
-    h->evs.clear();
-    if (h->aux) { (void)hipStreamDestroy(h->aux); h->aux = nullptr; }
 }
 
 }  // namespace
@@ -756,10 +586,6 @@ int ptycho_create(ptycho_handle* out, size_t ptheta, size_t nz, size_t n, size_t
     if (env) h->use_window = std::atoi(env) != 0;
     env = std::getenv("PTYCHO_HIP_SPLIT");
     if (env) h->use_split = std::atoi(env) != 0;
-    env = std::getenv("PTYCHO_HIP_PIPELINE");
-    if (env) h->use_pipeline = std::atoi(env) != 0;
-    env = std::getenv("PTYCHO_HIP_TEAM");
-    if (env) h->use_team = std::atoi(env) != 0;
     env = std::getenv("PTYCHO_HIP_FUSED");
     if (env) h->use_fused = std::atoi(env);
     h->chunk = default_chunk(h->ge);
@@ -801,13 +627,6 @@ long long ptycho_get(ptycho_handle h, int which) {
         case 5: return h->ge.nprb;
         case 100: return h->chunk;
         case 101: return h->use_window;
-        case 102: {   // team abort word of the last team launch (synchronises the device)
-            if (!h->ctrl) return 0;
-            unsigned w = 0;
-            if (hipDeviceSynchronize() != hipSuccess) return -2;
-            if (hipMemcpy(&w, h->ctrl + 9, sizeof(unsigned), hipMemcpyDeviceToHost) != hipSuccess) return -2;
-            return (long long)w;
-        }
         default: return -1;
     }
 }
@@ -832,14 +651,6 @@ int ptycho_set_option(ptycho_handle h, const char* name, long long value) {
     }
     if (std::strcmp(name, "split") == 0) {
         h->use_split = value != 0;
-        return PTYCHO_OK;
-    }
-    if (std::strcmp(name, "pipeline") == 0) {
-        h->use_pipeline = value != 0;
-        return PTYCHO_OK;
-    }
-    if (std::strcmp(name, "team") == 0) {
-        h->use_team = value != 0;
         return PTYCHO_OK;
     }
     if (std::strcmp(name, "fused") == 0) {

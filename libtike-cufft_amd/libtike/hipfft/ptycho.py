@@ -127,7 +127,7 @@ class PtychoHIP:
             nat.check(nat.free(self._h))
 
     def set_chunk(self, positions):
-        """Positions per launch pair (0 = default, about 64 MiB of farplane)."""
+        """Positions per launch pair of the adjoint (0 = default: at most 4 GiB of scratch)."""
         nat.check(nat.set_option(self._h, b"chunk", int(positions)))
 
     def set_window(self, on=True):
@@ -138,17 +138,9 @@ class PtychoHIP:
         """ndet = 256: split the DFT over y between the column and the row pass (default on)."""
         nat.check(nat.set_option(self._h, b"split", int(bool(on))))
 
-    def set_pipeline(self, on=True):
-        """Chunked two-stream overlap of column and row passes (experimental, off by default)."""
-        nat.check(nat.set_option(self._h, b"pipeline", int(bool(on))))
-
-    def set_team(self, on=True):
-        """Forward operator as one persistent XCD-team launch (experimental)."""
-        nat.check(nat.set_option(self._h, b"team", int(bool(on))))
-
-    def team_aborted(self):
-        """True if the last team launch hit a spin bound (results are then invalid)."""
-        return int(nat.get(self._h, 102)) != 0
+    def set_fused(self, tiles=2):
+        """ndet = 256: forward operator as one launch (``k_fwd_fused256``), ``tiles`` = 0 (off), 1 or 2."""
+        nat.check(nat.set_option(self._h, b"fused", int(tiles)))
 
     def profile(self, enable=True):
         """Bracket every kernel launch with HIP events (bench.py's live timing)."""
