@@ -144,6 +144,63 @@ int ptycho_cg_zoom(ptycho_handle h, const void* image_product, const void* best,
                    const void* lz, int nc, int ups, double upsample_factor, void* shifts,
                    void* stream);
 
+/* ---- device-resident CG iteration (native sequencing of ptycho.py:325-465) -----------------------
+ * The reference decides every line-search trial on the host and runs the object- / probe-sized
+ * stages (probe rescale, gradient normalisation, Dai-Yuan direction, updates) as dozens of small
+ * array kernels per iteration.  Here they are HIP kernels driven by a float64 STATE vector that
+ * lives on the device (owned by the caller, PTYCHO_CG_STATE_WORDS doubles, zero-initialised once),
+ * and an iteration is issued as a few stage calls with no device synchronisation.  Between the
+ * stages a multi-GPU caller all-reduces (sum) the words / arrays named below; a single-GPU caller
+ * just calls them back to back.  One probe mode, gaussian model, ptheta = 1 for the position step.
+ *
+ *   ptycho_cg_obj_begin   state[A,B,COST..] <- 0; slot 0 <- column pass of fwd(psi, probe); state[A,B] += statistics
+ *                         (ptycho.py:330-343).                       all-reduce: state[PTYCHO_ST_A .. +2)
+ *   ptycho_cg_obj_grad    probe *= a/b (:344); slot 1 <- projected residual, state[COST] += cost (:347-353);
+ *                         grad <- adj (raw, not yet divided by max|probe|^2).   all-reduce: grad
+ *   ptycho_cg_obj_dir     grad /= max|probe|^2 (:356); Dai-Yuan dpsi, grad0 <- grad (:366-373); slot 1 <- column
+ *                         pass of fwd(dpsi, probe); first line-search pass (:383-393).
+ *                                                                    all-reduce: state[PTYCHO_ST_COSTS .. +102)
+ *   ptycho_cg_ls_next     decide on the pass just reduced (line_search_sqr, :253-281); pass = 1, 2: issue the next
+ *                         pass (16, then 96 step lengths; each returns at once when the search is already
+ *                         resolved) -> all-reduce state[COSTS..] again; pass = 3: decide only.  The accepted
+ *                         step length times 0.5 lands in state[GAMMA_PSI] (which = 0) / state[GAMMA_PRB] (which = 1).
+ *   ptycho_cg_obj_finish  i > 0: position correction (:398-403; needs the zoom factors of ptycho_cg_zoom), scan[0] += shifts;
+ *                         psi += gamma dpsi (:405)
+ *   ptycho_cg_prb_grad    slot 0 <- column pass of fwd(psi, probe); slot 1 <- projected residual (:421-430);
+ *                         gprb <- adj_probe (raw).                   all-reduce: gprb
+ *   ptycho_cg_prb_dir     gprb <- gprb / max|psi|^2 / nscan_total * nmodes (:431); Dai-Yuan dprb (:437-448);
+ *                         slot 1 <- column pass of fwd(psi, dprb); first line-search pass (:451-461).
+ *   ptycho_cg_prb_finish  probe += gamma dprb (:465)
+ * state[PTYCHO_ST_LS_FAILED] counts failed line searches ("Line search failed for conjugate gradient."). */
+enum {
+    PTYCHO_ST_A = 0, PTYCHO_ST_B = 1,           /* sum sqrt(I d), sum I                       */
+    PTYCHO_ST_COST = 2, PTYCHO_ST_COST2 = 3,    /* start-of-iteration cost; probe-step scratch */
+    PTYCHO_ST_DY_OBJ = 4, PTYCHO_ST_DY_PRB = 7, /* 3 words each: ||g||^2, Re, Im sum conj(d)(g - g0) */
+    PTYCHO_ST_MAX_PRB = 10, PTYCHO_ST_MAX_PSI = 11,   /* float bits of max|.| in the low half of the word */
+    PTYCHO_ST_ZEROED = 12,                      /* words [0, 12) are cleared by ptycho_cg_obj_begin */
+    PTYCHO_ST_GAMMA_PSI = 12, PTYCHO_ST_GAMMA_PRB = 13,
+    PTYCHO_ST_LS_GAMMA0 = 14, PTYCHO_ST_LS_NCAND = 15, PTYCHO_ST_LS_NGROUPS = 16, PTYCHO_ST_LS_TRIED = 17,
+    PTYCHO_ST_LS_RESOLVED = 18, PTYCHO_ST_LS_FAILED = 19,
+    PTYCHO_ST_HINT = 20,                        /* [2] accepted index of the last object / probe search (seed with 14) */
+    PTYCHO_ST_COSTS = 24,                       /* 6 groups x (16 step lengths + f(p1)) */
+    PTYCHO_CG_STATE_WORDS = 128
+};
+int ptycho_cg_obj_begin(ptycho_handle h, double* state, const void* psi, const void* scan, const void* prb,
+                        const void* data, void* stream);
+int ptycho_cg_obj_grad(ptycho_handle h, double* state, const void* scan, void* prb, const void* data, void* grad,
+                       void* stream);
+int ptycho_cg_obj_dir(ptycho_handle h, double* state, int first, const void* scan, const void* prb, const void* data,
+                      void* grad, void* grad0, void* dpsi, void* stream);
+int ptycho_cg_ls_next(ptycho_handle h, double* state, int which, int pass, const void* data, int use_ab, void* stream);
+int ptycho_cg_obj_finish(ptycho_handle h, double* state, int correct_positions, void* psi, const void* dpsi, void* scan,
+                         const void* ones_prb, const void* vt, const void* lz, int nc, int ups, double upsample_factor,
+                         void* stream);
+int ptycho_cg_prb_grad(ptycho_handle h, double* state, const void* psi, const void* scan, const void* prb,
+                       const void* data, void* gprb, void* stream);
+int ptycho_cg_prb_dir(ptycho_handle h, double* state, int first, double nscan_total, double nmodes, const void* psi,
+                      const void* scan, const void* data, void* gprb, void* gprb0, void* dprb, void* stream);
+int ptycho_cg_prb_finish(ptycho_handle h, double* state, void* prb, const void* dprb, void* stream);
+
 /* Tuning knobs: "chunk" (positions per launch pair, 0 = default);
  * "window" (1 = LDS overlap-add object adjoint [default], 0 = direct atomics);
  * "trust_order" (1 = the caller vouches that the scan buffer passed to the next calls is the

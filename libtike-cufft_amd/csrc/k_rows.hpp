@@ -188,6 +188,11 @@ struct RowFusedArgs {
     const c32* sm[2 * kMaxModes];
     int nmodes;
     c32* ip;             // EP_CROSS: image product u1 * conj(u2), [positions][ndet][ndet]
+    // device-resident CG state (k_cg_small.hpp; nullptr: the host arguments above are used).  Line search: the
+    // pass returns at once if the search is resolved, reads gamma0 / ncand / ngroups from the state and adds the
+    // costs of group grp to st[PTYCHO_ST_COSTS + 17 grp ...]; EP_CROSS: gamma = *gamma_dev.
+    double* st;
+    const double* gamma_dev;
 };
 
 template <int N, int EP>
@@ -223,6 +228,18 @@ __global__ __launch_bounds__(256) void k_rows_fused(const RowFusedArgs a) {
         sinv = bf / af;
     }
 
+    float gamma0 = a.gamma0;
+    int ncand = a.ncand, ngroups = 1;
+    double* sums = a.sums;
+    if (LS && a.st) {
+        if (a.st[PTYCHO_ST_LS_RESOLVED] != 0.0) return;   // uniform over the grid
+        gamma0 = (float)a.st[PTYCHO_ST_LS_GAMMA0];
+        ncand = (int)a.st[PTYCHO_ST_LS_NCAND];
+        ngroups = (int)a.st[PTYCHO_ST_LS_NGROUPS];
+        sums = a.st + PTYCHO_ST_COSTS;
+    }
+    if (EP == EP_CROSS && a.gamma_dev) gamma0 = (float)*a.gamma_dev;
+
     // forward DFT over x of one row held as step-0 inputs in v; result in natural order
     auto fwd_row = [&](c32* v, c32* nat) {
         fft.template compute<0>(v);
@@ -244,6 +261,14 @@ __global__ __launch_bounds__(256) void k_rows_fused(const RowFusedArgs a) {
     };
 
     const long long nb = (a.nrows + B - 1) / B;
+    for (int grp = 0; grp < ngroups; ++grp) {   // line search: groups of 16 step lengths, one sweep each (else one pass)
+    const float gam_first = gamma0 * exp2f(-16.0f * (float)grp);
+    if (grp > 0) {
+#pragma unroll
+        for (int i = 0; i < NACC; ++i) acc[i] = 0.0f;
+#pragma unroll
+        for (int i = 0; i < (LS ? NACC : 1); ++i) acc2[i] = c32{0.0f, 0.0f};
+    }
     for (long long batch = blockIdx.x; batch < nb; batch += gridDim.x) {
         const long long r = batch * B + f;
         const bool ok = r < a.nrows;
@@ -276,7 +301,7 @@ __global__ __launch_bounds__(256) void k_rows_fused(const RowFusedArgs a) {
             for (int m = 0; m < E; ++m) g1[m] = stash[m * 256 + tid];
 #pragma unroll
             for (int m = 0; m < E; ++m) {
-                const c32 u2 = g1[m] + g2[m] * a.gamma0;
+                const c32 u2 = g1[m] + g2[m] * gamma0;
                 rr[m] = cmulc(g1[m], u2);
                 if (ok) __builtin_nontemporal_store(rr[m], a.ip + boff + (fN + (unsigned)(j0 + m * T)));
             }
@@ -407,10 +432,10 @@ __global__ __launch_bounds__(256) void k_rows_fused(const RowFusedArgs a) {
                 const c32 sd = c32{fsqrt(d[m]), fsqrt(d[m + 1])};
                 c32 df = c32{fsqrt(fabsf(q1.x)), fsqrt(fabsf(q1.y))} - sd;
                 acc2[kMaxCand] += df * df;
-                float gam = a.gamma0;
+                float gam = gam_first;
 #pragma unroll
                 for (int j0c = 0; j0c < kMaxCand; j0c += 4) {
-                    if (j0c < a.ncand) {
+                    if (j0c < ncand) {
 #pragma unroll
                         for (int j = j0c; j < j0c + 4; ++j) {
                             const c32 xx = q1 + q2 * (gam * gam) + q3 * gam;
@@ -438,10 +463,10 @@ __global__ __launch_bounds__(256) void k_rows_fused(const RowFusedArgs a) {
                 const c32 sd = c32{fsqrt(d[m]), fsqrt(d[m + 1])};
                 c32 df = c32{fsqrt(fabsf(p1.x)), fsqrt(fabsf(p1.y))} - sd;
                 acc2[kMaxCand] += df * df;
-                float gam = a.gamma0;
+                float gam = gam_first;
 #pragma unroll
                 for (int j0c = 0; j0c < kMaxCand; j0c += 4) {
-                    if (j0c < a.ncand) {
+                    if (j0c < ncand) {
 #pragma unroll
                         for (int j = j0c; j < j0c + 4; ++j) {
                             const c32 xx = p1 + p2 * (gam * gam) + p3 * gam;
@@ -472,7 +497,10 @@ __global__ __launch_bounds__(256) void k_rows_fused(const RowFusedArgs a) {
     __syncthreads();
     if (tid < NACC) {
         const double x = red[tid] + red[NACC + tid] + red[2 * NACC + tid] + red[3 * NACC + tid];
-        if (!LS || tid < a.ncand || tid == kMaxCand)
-            atomicAdd(a.sums + (LS && tid == kMaxCand ? a.ncand : tid), x);
+        double* out = sums + (LS ? grp * (kMaxCand + 1) : 0);
+        if (!LS || tid < ncand || tid == kMaxCand)
+            atomicAdd(out + (LS && tid == kMaxCand ? ncand : tid), x);
     }
+    __syncthreads();
+    }   // grp
 }

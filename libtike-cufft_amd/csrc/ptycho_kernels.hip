@@ -41,6 +41,8 @@ namespace {
 #include "k_rows.hpp"
 #include "k_cols_window.hpp"
 #include "k_fwd_fused.hpp"
+#include "k_cg_small.hpp"
+#include "k_generic.hpp"
 #include "k_zoom.hpp"
 
 // ---------------------------------------------------------------------------
@@ -67,7 +69,10 @@ int fail(int code, const std::string& msg) {
 
 struct ptycho_handle_s {
     Geom ge;
-    c32* table = nullptr;     // exp(-2 pi i k / ndet)
+    c32* table = nullptr;     // exp(-2 pi i k / ndet)  (ndet not a power of two: k / bs_m)
+    int bs_m = 0;             // 0: ndet is a power of two; else length of the Bluestein plan (k_generic.hpp)
+    c32* bs_chirp = nullptr;  // exp(-i pi m^2 / ndet), m < ndet
+    c32* bs_hfilt = nullptr;  // FFT_M of the circular conj-chirp, divided by M
     c32* scratch = nullptr;   // chunk * ndet^2 complex64
     long long chunk = 0;      // positions per launch pair
     // position sort (object / probe adjoint)
@@ -76,6 +81,9 @@ struct ptycho_handle_s {
     static constexpr int kSlots = 2 * kMaxModes;
     c32* work[kSlots] = {};   // CG work buffers (column-pass intermediates), all positions; 0/1 + per-mode pairs
     void* zoom_phase = nullptr;           // registration: per-pattern phases + whole-pixel shifts
+    c32* reg_ip = nullptr;                // native CG loop: image product of the registration [positions][ndet][ndet]
+    unsigned long long* reg_best = nullptr;   // whole-pixel peaks [positions]
+    double* reg_shifts = nullptr;         // sub-pixel shifts [positions][2]
     int use_window = 1;       // 0: direct-atomics object adjoint (k_cols<ADJ_OBJ>)
     int use_split = 1;        // ndet = 256: one radix-16 step of the DFT over y runs in the row pass
     int use_fused = 0;        // ndet = 256 forward as one launch (k_fwd_fused256): 0 off (default: measured slower), 1 / 2 class tiles per pass
@@ -407,6 +415,7 @@ int ensure_work(ptycho_handle h, int slot) {
     if (!h->work[slot]) {
         const size_t total = (size_t)h->ge.ptheta * h->ge.nscan;
         HIP_TRY(hipMalloc((void**)&h->work[slot], total * h->ge.ndet * h->ge.ndet * sizeof(c32)));
+        HIP_TRY(hipMemset(h->work[slot], 0, total * h->ge.ndet * h->ge.ndet * sizeof(c32)));
     }
     return PTYCHO_OK;
 }
@@ -485,6 +494,79 @@ int do_cg_rows(ptycho_handle h, RowFusedArgs a, hipStream_t st) {
     return PTYCHO_OK;
 }
 
+
+// ---- detector sizes that are not a power of two (k_generic.hpp) ------------------------------------
+template <int M, int DIR>
+int launch_lines(ptycho_handle h, const c32* src, c32* dst, long long ntiles, bool columns, const int* tile_index, hipStream_t st) {
+    const int n = h->ge.ndet;
+    LineArgs a{};
+    a.src = src; a.dst = dst; a.table = h->table; a.chirp = h->bs_chirp; a.hfilt = h->bs_hfilt;
+    a.nlines = ntiles * n; a.n = n; a.ls = columns ? 1 : n; a.es = columns ? n : 1; a.tile_index = tile_index;
+    constexpr int T = Plan<M>::T, B = (256 / T) > 0 ? (256 / T) : 1;
+    const long long nb = (a.nlines + B - 1) / B;
+    const long long grid = nb < (long long)h->n_cu * 8 ? nb : (long long)h->n_cu * 8;
+    {
+        ProfSpan ps(h, DIR < 0 ? K_ROWS_FWD : K_ROWS_INV, st);
+        hipLaunchKernelGGL((k_lines_bluestein<M, DIR>), dim3((unsigned)grid), dim3(256), 0, st, a);
+    }
+    HIP_TRY(hipGetLastError());
+    return PTYCHO_OK;
+}
+
+template <int M>
+int do_fwd_generic(ptycho_handle h, c32* g, const c32* f, const float* scan, const c32* prb, hipStream_t st) {
+    const Geom& ge = h->ge;
+    const long long total = (long long)ge.ptheta * ge.nscan;
+    const long long npix = total * ge.ndet * ge.ndet;
+    {
+        ProfSpan ps(h, K_COLS_FWD, st);
+        hipLaunchKernelGGL(k_near_generic, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, st, f, prb, scan, g, ge, npix);
+    }
+    HIP_TRY(hipGetLastError());
+    int rc = launch_lines<M, -1>(h, g, g, total, false, nullptr, st);
+    if (rc) return rc;
+    return launch_lines<M, -1>(h, g, g, total, true, nullptr, st);
+}
+
+template <int M>
+int do_adj_generic(ptycho_handle h, c32* f, const c32* g, const float* scan, c32* prb, int flg, hipStream_t st) {
+    const Geom& ge = h->ge;
+    const long long total = (long long)ge.ptheta * ge.nscan;
+    const size_t tile = (size_t)ge.ndet * ge.ndet;
+    for (long long k0 = 0; k0 < total; k0 += h->chunk) {
+        const long long k1 = k0 + h->chunk < total ? k0 + h->chunk : total;
+        int rc = launch_lines<M, +1>(h, g + (size_t)k0 * tile, h->scratch, k1 - k0, false, nullptr, st);
+        if (rc) return rc;
+        rc = launch_lines<M, +1>(h, h->scratch, h->scratch, k1 - k0, true, nullptr, st);
+        if (rc) return rc;
+        if (flg == 0) {
+            const long long npix = (k1 - k0) * ge.nprb * ge.nprb;
+            ProfSpan ps(h, K_COLS_ADJ_OBJ, st);
+            hipLaunchKernelGGL(k_adj_obj_generic, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, st, f, (const c32*)prb, scan,
+                               (const c32*)h->scratch, ge, (int)k0, npix);
+        } else {
+            const int npp = ge.nprb * ge.nprb;
+            int groups = (int)((k1 - k0 + 63) / 64);
+            if (groups > 1024) groups = 1024;
+            const int pgroup = (int)((k1 - k0 + groups - 1) / groups);
+            ProfSpan ps(h, K_COLS_ADJ_PRB, st);
+            hipLaunchKernelGGL(k_adj_prb_generic, dim3((unsigned)((npp + 255) / 256), (unsigned)groups), dim3(256), 0, st,
+                               (const c32*)f, prb, scan, (const c32*)h->scratch, ge, (int)k0, (int)k1, pgroup);
+        }
+        HIP_TRY(hipGetLastError());
+    }
+    return PTYCHO_OK;
+}
+
+template <int M>
+int do_fft2_generic(ptycho_handle h, c32* dst, const c32* src, long long nbatch, int dir, hipStream_t st) {
+    int rc = dir < 0 ? launch_lines<M, -1>(h, src, dst, nbatch, false, nullptr, st)
+                     : launch_lines<M, +1>(h, src, dst, nbatch, false, nullptr, st);
+    if (rc) return rc;
+    return dir < 0 ? launch_lines<M, -1>(h, dst, dst, nbatch, true, nullptr, st)
+                   : launch_lines<M, +1>(h, dst, dst, nbatch, true, nullptr, st);
+}
+
 #define PTY_DISPATCH(N_, CALL)                                   \
     switch (N_) {                                                \
         case 16: { constexpr int NN = 16; return CALL; }         \
@@ -495,7 +577,7 @@ int do_cg_rows(ptycho_handle h, RowFusedArgs a, hipStream_t st) {
         case 512: { constexpr int NN = 512; return CALL; }       \
         case 1024: { constexpr int NN = 1024; return CALL; }     \
         case 2048: { constexpr int NN = 2048; return CALL; }     \
-        default: return fail(PTYCHO_ERR_ARG, "ndet must be a power of two in [16, 2048]"); \
+        default: return fail(PTYCHO_ERR_ARG, "this entry point needs a power-of-two detector size in [16, 2048]"); \
     }
 
 int check_handle(ptycho_handle h) {
@@ -533,8 +615,8 @@ int alloc_sort(ptycho_handle h) {
 }
 
 void release(ptycho_handle h) {
-    void* ptrs[] = {h->table, h->scratch, h->order, h->sort_counts, h->zoom_phase, h->prbp};
-    h->zoom_phase = nullptr; h->prbp = nullptr;
+    void* ptrs[] = {h->bs_chirp, h->bs_hfilt, h->table, h->scratch, h->order, h->sort_counts, h->zoom_phase, h->prbp, h->reg_ip, h->reg_best, h->reg_shifts};
+    h->zoom_phase = nullptr; h->prbp = nullptr; h->bs_chirp = nullptr; h->bs_hfilt = nullptr; h->reg_ip = nullptr; h->reg_best = nullptr; h->reg_shifts = nullptr;
     for (auto& w : h->work) { if (w) (void)hipFree(w); w = nullptr; }
     for (void* q : ptrs)
         if (q) (void)hipFree(q);
@@ -555,8 +637,9 @@ int ptycho_create(ptycho_handle* out, size_t ptheta, size_t nz, size_t n, size_t
     *out = nullptr;
     if (ptheta == 0 || nz == 0 || n == 0 || nscan == 0 || ndet == 0 || nprb == 0)
         return fail(PTYCHO_ERR_ARG, "all sizes must be positive");
-    if (ndet < 16 || ndet > 2048 || (ndet & (ndet - 1)) != 0)
-        return fail(PTYCHO_ERR_ARG, "ndet must be a power of two in [16, 2048]");
+    const bool pow2 = (ndet & (ndet - 1)) == 0 && ndet >= 16;
+    if (ndet < 2 || ndet > 2048 || (!pow2 && ndet > 1024))
+        return fail(PTYCHO_ERR_ARG, "ndet must be in [2, 1024], or a power of two up to 2048");
     if (nprb > ndet) return fail(PTYCHO_ERR_ARG, "nprb must be <= ndet");
     if (ptheta * nscan > (size_t)0x7fffffff / 2 || ptheta > (1u << 19) || nz > 65536 * 4 || n > 65536 * 4)
         return fail(PTYCHO_ERR_ARG, "problem too large for 32-bit position indices");
@@ -570,13 +653,47 @@ int ptycho_create(ptycho_handle* out, size_t ptheta, size_t nz, size_t n, size_t
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, h->device) == hipSuccess && prop.multiProcessorCount > 0)
         h->n_cu = prop.multiProcessorCount;
-    std::vector<c32> tab(ndet);
-    for (size_t k = 0; k < ndet; ++k) {
-        const double ang = -2.0 * M_PI * (double)k / (double)ndet;
+    size_t tlen = ndet;
+    if (!pow2) {   // Bluestein plan: smallest power of two >= 2 ndet - 1 (and >= 16)
+        tlen = 16;
+        while (tlen < 2 * ndet - 1) tlen *= 2;
+        h->bs_m = (int)tlen;
+    }
+    std::vector<c32> tab(tlen);
+    for (size_t k = 0; k < tlen; ++k) {
+        const double ang = -2.0 * M_PI * (double)k / (double)tlen;
         tab[k] = c32{(float)std::cos(ang), (float)std::sin(ang)};
     }
-    e = hipMalloc((void**)&h->table, ndet * sizeof(c32));
-    if (e == hipSuccess) e = hipMemcpy(h->table, tab.data(), ndet * sizeof(c32), hipMemcpyHostToDevice);
+    e = hipMalloc((void**)&h->table, tlen * sizeof(c32));
+    if (e == hipSuccess) e = hipMemcpy(h->table, tab.data(), tlen * sizeof(c32), hipMemcpyHostToDevice);
+    if (e == hipSuccess && !pow2) {
+        // chirp b[m] = exp(-i pi m^2 / n) (phase reduced modulo 2 n exactly) and H = FFT_M(conj b, circular) / M in float64
+        const size_t n = ndet, M = tlen;
+        std::vector<double> br(n), bi(n), hr(M, 0.0), hi(M, 0.0), Hr(M), Hi(M);
+        std::vector<c32> bf(n), Hf(M);
+        for (size_t m = 0; m < n; ++m) {
+            const double ang = -M_PI * (double)((m * m) % (2 * n)) / (double)n;
+            br[m] = std::cos(ang); bi[m] = std::sin(ang);
+            bf[m] = c32{(float)br[m], (float)bi[m]};
+            hr[m] = br[m]; hi[m] = -bi[m];
+            if (m) { hr[M - m] = br[m]; hi[M - m] = -bi[m]; }
+        }
+        for (size_t k = 0; k < M; ++k) {   // plain O(M^2) DFT, once per handle (M <= 2048)
+            double sr = 0.0, si = 0.0;
+            for (size_t m = 0; m < M; ++m) {
+                if (hr[m] == 0.0 && hi[m] == 0.0) continue;
+                const double ang = -2.0 * M_PI * (double)((k * m) % M) / (double)M;
+                const double c = std::cos(ang), s2 = std::sin(ang);
+                sr += hr[m] * c - hi[m] * s2;
+                si += hr[m] * s2 + hi[m] * c;
+            }
+            Hf[k] = c32{(float)(sr / (double)M), (float)(si / (double)M)};
+        }
+        e = hipMalloc((void**)&h->bs_chirp, n * sizeof(c32));
+        if (e == hipSuccess) e = hipMemcpy(h->bs_chirp, bf.data(), n * sizeof(c32), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMalloc((void**)&h->bs_hfilt, M * sizeof(c32));
+        if (e == hipSuccess) e = hipMemcpy(h->bs_hfilt, Hf.data(), M * sizeof(c32), hipMemcpyHostToDevice);
+    }
     if (e != hipSuccess) {
         release(h);
         delete h;
@@ -690,6 +807,7 @@ int ptycho_fwd(ptycho_handle h, void* g, const void* f, const void* scan, const 
     if (rc) return rc;
     if (!g || !f || !scan || !prb) return fail(PTYCHO_ERR_ARG, "null operand");
     hipStream_t st = (hipStream_t)stream;
+    if (h->bs_m) { PTY_DISPATCH(h->bs_m, (do_fwd_generic<NN>(h, (c32*)g, (const c32*)f, (const float*)scan, (const c32*)prb, st))); }
     PTY_DISPATCH(h->ge.ndet, (do_fwd<NN>(h, (c32*)g, (const c32*)f, (const float*)scan, (const c32*)prb, st)));
 }
 
@@ -699,6 +817,7 @@ int ptycho_adj(ptycho_handle h, void* f, const void* g, const void* scan, void* 
     if (!g || !f || !scan || !prb) return fail(PTYCHO_ERR_ARG, "null operand");
     if (flg != 0 && flg != 1) return fail(PTYCHO_ERR_ARG, "flg must be 0 (object) or 1 (probe)");
     hipStream_t st = (hipStream_t)stream;
+    if (h->bs_m) { PTY_DISPATCH(h->bs_m, (do_adj_generic<NN>(h, (c32*)f, (const c32*)g, (const float*)scan, (c32*)prb, flg, st))); }
     PTY_DISPATCH(h->ge.ndet, (do_adj<NN>(h, (c32*)f, (const c32*)g, (const float*)scan, (c32*)prb, flg, st)));
 }
 
@@ -825,6 +944,7 @@ int ptycho_fft2(ptycho_handle h, void* dst, const void* src, size_t nbatch, int 
     if (dir != -1 && dir != 1) return fail(PTYCHO_ERR_ARG, "dir must be -1 (forward) or +1 (inverse)");
     if (nbatch == 0) return PTYCHO_OK;
     hipStream_t st = (hipStream_t)stream;
+    if (h->bs_m) { PTY_DISPATCH(h->bs_m, (do_fft2_generic<NN>(h, (c32*)dst, (const c32*)src, (long long)nbatch, dir, st))); }
     PTY_DISPATCH(h->ge.ndet, (do_fft2<NN>(h, (c32*)dst, (const c32*)src, (long long)nbatch, dir, st)));
 }
 
@@ -887,6 +1007,7 @@ extern "C" int ptycho_cg_zoom(ptycho_handle h, const void* image_product, const 
     hipStream_t st = (hipStream_t)stream;
     if (!h->zoom_phase) {   // px, py: complex128 [npos][N] each; coarse shifts: float64 [npos][2]
         HIP_TRY(hipMalloc(&h->zoom_phase, (size_t)npos * N * 2 * sizeof(double2) + (size_t)npos * 2 * sizeof(double)));
+        HIP_TRY(hipMemset(h->zoom_phase, 0, (size_t)npos * N * 2 * sizeof(double2) + (size_t)npos * 2 * sizeof(double)));
     }
     double2* ppx = (double2*)h->zoom_phase;
     double2* ppy = ppx + (size_t)npos * N;
@@ -919,3 +1040,198 @@ extern "C" int ptycho_cg_zoom(ptycho_handle h, const void* image_product, const 
     HIP_TRY(hipGetLastError());
     return PTYCHO_OK;
 }
+
+
+// ---------------------------------------------------------------------------------------------------
+// Native CG stages (include/ptycho_hip.h, "device-resident CG iteration")
+// ---------------------------------------------------------------------------------------------------
+namespace {
+
+inline unsigned small_grid(ptycho_handle h, long long n) {
+    long long g = (n + 255) / 256;
+    const long long cap = (long long)h->n_cu * 4;
+    if (g > cap) g = cap;
+    return (unsigned)(g < 1 ? 1 : g);
+}
+
+template <int N>
+int do_ls_pass(ptycho_handle h, const float* data, const double* ab, double* state, hipStream_t st) {
+    RowFusedArgs a{};
+    a.s1 = h->work[0]; a.s2 = h->work[1]; a.data = data; a.ab = ab; a.st = state;
+    a.sums = state + PTYCHO_ST_COSTS; a.gamma0 = 1.0f; a.ncand = kMaxCand;
+    return do_cg_rows<N, EP_LINESEARCH>(h, a, st);
+}
+int ls_pass(ptycho_handle h, const void* data, int use_ab, double* state, hipStream_t st) {
+    if (!slot_ready(h, 0) || !slot_ready(h, 1)) return fail(PTYCHO_ERR_ARG, "work slot is empty");
+    const double* ab = use_ab ? state + PTYCHO_ST_A : nullptr;
+    PTY_DISPATCH(h->ge.ndet, (do_ls_pass<NN>(h, (const float*)data, ab, state, st)));
+}
+
+template <int N>
+int do_cross_dev(ptycho_handle h, const double* gamma_dev, hipStream_t st) {
+    RowFusedArgs a{};
+    a.s1 = h->work[0]; a.s2 = h->work[1]; a.out = h->work[1]; a.ip = h->reg_ip; a.gamma_dev = gamma_dev;
+    return do_cg_rows<N, EP_CROSS>(h, a, st);
+}
+int cross_dev(ptycho_handle h, const double* gamma_dev, hipStream_t st) {
+    PTY_DISPATCH(h->ge.ndet, (do_cross_dev<NN>(h, gamma_dev, st)));
+}
+
+int check_stage(ptycho_handle h, const void* state) {
+    int rc = check_handle(h);
+    if (rc) return rc;
+    if (!state) return fail(PTYCHO_ERR_ARG, "null state");
+    return PTYCHO_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ptycho_cg_obj_begin(ptycho_handle h, double* state, const void* psi, const void* scan, const void* prb,
+                        const void* data, void* stream) {
+    int rc = check_stage(h, state);
+    if (rc) return rc;
+    if (!psi || !scan || !prb || !data) return fail(PTYCHO_ERR_ARG, "null operand");
+    hipStream_t st = (hipStream_t)stream;
+    h->trust_order = 1;   // the native loop keeps track of scan itself (ptycho_cg_obj_finish invalidates the order)
+    HIP_TRY(hipMemsetAsync(state, 0, PTYCHO_ST_ZEROED * sizeof(double), st));
+    rc = ptycho_cg_fwd_cols(h, 0, psi, scan, prb, stream);
+    if (rc) return rc;
+    return ptycho_cg_stats(h, 0, data, state + PTYCHO_ST_A, stream);
+}
+
+int ptycho_cg_obj_grad(ptycho_handle h, double* state, const void* scan, void* prb, const void* data, void* grad,
+                       void* stream) {
+    int rc = check_stage(h, state);
+    if (rc) return rc;
+    if (!scan || !prb || !data || !grad) return fail(PTYCHO_ERR_ARG, "null operand");
+    hipStream_t st = (hipStream_t)stream;
+    const Geom& ge = h->ge;
+    const long long np = (long long)ge.ptheta * ge.nprb * ge.nprb, no = (long long)ge.ptheta * ge.nz * ge.n;
+    hipLaunchKernelGGL(k_cg_scale_probe, dim3(small_grid(h, np)), dim3(256), 0, st, (c32*)prb, np, (const double*)state);
+    rc = ptycho_cg_project(h, 0, 1, data, state + PTYCHO_ST_A, state + PTYCHO_ST_COST, stream);
+    if (rc) return rc;
+    HIP_TRY(hipMemsetAsync(grad, 0, (size_t)no * sizeof(c32), st));
+    return ptycho_cg_adj_cols(h, 1, grad, scan, prb, 0, stream);
+}
+
+int ptycho_cg_obj_dir(ptycho_handle h, double* state, int first, const void* scan, const void* prb, const void* data,
+                      void* grad, void* grad0, void* dpsi, void* stream) {
+    int rc = check_stage(h, state);
+    if (rc) return rc;
+    if (!scan || !prb || !data || !grad || !grad0 || !dpsi) return fail(PTYCHO_ERR_ARG, "null operand");
+    hipStream_t st = (hipStream_t)stream;
+    const Geom& ge = h->ge;
+    const long long np = (long long)ge.ptheta * ge.nprb * ge.nprb, no = (long long)ge.ptheta * ge.nz * ge.n;
+    hipLaunchKernelGGL(k_cg_absmax, dim3(small_grid(h, np)), dim3(256), 0, st, (const c32*)prb, np, state + PTYCHO_ST_MAX_PRB);
+    hipLaunchKernelGGL(k_cg_dy_reduce, dim3(small_grid(h, no)), dim3(256), 0, st, (c32*)grad, (const c32*)dpsi, (const c32*)grad0, no,
+                       (const double*)(state + PTYCHO_ST_MAX_PRB), 0.0f, 0.0f, state + PTYCHO_ST_DY_OBJ, first);
+    hipLaunchKernelGGL(k_cg_dy_update, dim3(small_grid(h, no)), dim3(256), 0, st, (c32*)dpsi, (c32*)grad0, (const c32*)grad, no,
+                       (const double*)(state + PTYCHO_ST_DY_OBJ), first);
+    rc = ptycho_cg_fwd_cols(h, 1, dpsi, scan, prb, stream);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_cg_ls_prepare, dim3(1), dim3(1), 0, st, state, 0);
+    return ls_pass(h, data, 1, state, st);
+}
+
+int ptycho_cg_ls_next(ptycho_handle h, double* state, int which, int pass, const void* data, int use_ab, void* stream) {
+    int rc = check_stage(h, state);
+    if (rc) return rc;
+    if (which < 0 || which > 1 || pass < 1 || pass > 3 || !data) return fail(PTYCHO_ERR_ARG, "bad line-search stage");
+    hipStream_t st = (hipStream_t)stream;
+    const int next_groups = pass == 1 ? 1 : (pass == 2 ? kLsGroupsMax : 0);
+    hipLaunchKernelGGL(k_cg_ls_decide, dim3(1), dim3(1), 0, st, state, which,
+                       which == 0 ? (int)PTYCHO_ST_GAMMA_PSI : (int)PTYCHO_ST_GAMMA_PRB, next_groups);
+    HIP_TRY(hipGetLastError());
+    if (pass == 3) return PTYCHO_OK;
+    return ls_pass(h, data, use_ab, state, st);
+}
+
+int ptycho_cg_obj_finish(ptycho_handle h, double* state, int correct_positions, void* psi, const void* dpsi, void* scan,
+                         const void* ones_prb, const void* vt, const void* lz, int nc, int ups, double upsample_factor,
+                         void* stream) {
+    int rc = check_stage(h, state);
+    if (rc) return rc;
+    if (!psi || !dpsi || !scan) return fail(PTYCHO_ERR_ARG, "null operand");
+    hipStream_t st = (hipStream_t)stream;
+    const Geom& ge = h->ge;
+    const long long no = (long long)ge.ptheta * ge.nz * ge.n;
+    if (correct_positions) {
+        if (ge.ptheta != 1) return fail(PTYCHO_ERR_ARG, "native position correction needs ptheta = 1");
+        if (!ones_prb || !vt || !lz) return fail(PTYCHO_ERR_ARG, "null operand");
+        const size_t npos = (size_t)ge.nscan;
+        if (!h->reg_ip) {
+            HIP_TRY(hipMalloc((void**)&h->reg_ip, npos * ge.ndet * ge.ndet * sizeof(c32)));
+            HIP_TRY(hipMalloc((void**)&h->reg_best, npos * sizeof(unsigned long long)));
+            HIP_TRY(hipMalloc((void**)&h->reg_shifts, npos * 2 * sizeof(double)));
+        }
+        // ptycho.py:399-402: tmp1 = fwd(psi, 1), tmp2 = fwd(psi + gamma dpsi, 1) = tmp1 + gamma fwd(dpsi, 1)
+        rc = ptycho_cg_fwd_cols(h, 0, psi, scan, ones_prb, stream);
+        if (rc) return rc;
+        rc = ptycho_cg_fwd_cols(h, 1, dpsi, scan, ones_prb, stream);
+        if (rc) return rc;
+        rc = cross_dev(h, state + PTYCHO_ST_GAMMA_PSI, st);
+        if (rc) return rc;
+        rc = ptycho_cg_argmax(h, 1, h->reg_best, stream);
+        if (rc) return rc;
+        rc = ptycho_cg_zoom(h, h->reg_ip, h->reg_best, vt, lz, nc, ups, upsample_factor, h->reg_shifts, stream);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_cg_add_shifts, dim3((unsigned)((2 * npos + 255) / 256)), dim3(256), 0, st, (float*)scan,
+                           (const double*)h->reg_shifts, (int)(2 * npos));
+        h->order_scan = nullptr;   // the positions moved: the next column pass sorts again
+    }
+    hipLaunchKernelGGL(k_cg_axpy, dim3(small_grid(h, no)), dim3(256), 0, st, (c32*)psi, (const c32*)dpsi, no,
+                       (const double*)(state + PTYCHO_ST_GAMMA_PSI));
+    HIP_TRY(hipGetLastError());
+    return PTYCHO_OK;
+}
+
+int ptycho_cg_prb_grad(ptycho_handle h, double* state, const void* psi, const void* scan, const void* prb,
+                       const void* data, void* gprb, void* stream) {
+    int rc = check_stage(h, state);
+    if (rc) return rc;
+    if (!psi || !scan || !prb || !data || !gprb) return fail(PTYCHO_ERR_ARG, "null operand");
+    hipStream_t st = (hipStream_t)stream;
+    const Geom& ge = h->ge;
+    const long long np = (long long)ge.ptheta * ge.nprb * ge.nprb;
+    rc = ptycho_cg_fwd_cols(h, 0, psi, scan, prb, stream);
+    if (rc) return rc;
+    rc = ptycho_cg_project(h, 0, 1, data, nullptr, state + PTYCHO_ST_COST2, stream);
+    if (rc) return rc;
+    HIP_TRY(hipMemsetAsync(gprb, 0, (size_t)np * sizeof(c32), st));
+    return ptycho_cg_adj_cols(h, 1, (void*)psi, scan, gprb, 1, stream);
+}
+
+int ptycho_cg_prb_dir(ptycho_handle h, double* state, int first, double nscan_total, double nmodes, const void* psi,
+                      const void* scan, const void* data, void* gprb, void* gprb0, void* dprb, void* stream) {
+    int rc = check_stage(h, state);
+    if (rc) return rc;
+    if (!psi || !scan || !data || !gprb || !gprb0 || !dprb) return fail(PTYCHO_ERR_ARG, "null operand");
+    hipStream_t st = (hipStream_t)stream;
+    const Geom& ge = h->ge;
+    const long long np = (long long)ge.ptheta * ge.nprb * ge.nprb, no = (long long)ge.ptheta * ge.nz * ge.n;
+    hipLaunchKernelGGL(k_cg_absmax, dim3(small_grid(h, no)), dim3(256), 0, st, (const c32*)psi, no, state + PTYCHO_ST_MAX_PSI);
+    hipLaunchKernelGGL(k_cg_dy_reduce, dim3(small_grid(h, np)), dim3(256), 0, st, (c32*)gprb, (const c32*)dprb, (const c32*)gprb0, np,
+                       (const double*)(state + PTYCHO_ST_MAX_PSI), (float)nscan_total, (float)nmodes, state + PTYCHO_ST_DY_PRB, first);
+    hipLaunchKernelGGL(k_cg_dy_update, dim3(small_grid(h, np)), dim3(256), 0, st, (c32*)dprb, (c32*)gprb0, (const c32*)gprb, np,
+                       (const double*)(state + PTYCHO_ST_DY_PRB), first);
+    rc = ptycho_cg_fwd_cols(h, 1, psi, scan, dprb, stream);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_cg_ls_prepare, dim3(1), dim3(1), 0, st, state, 1);
+    return ls_pass(h, data, 0, state, st);
+}
+
+int ptycho_cg_prb_finish(ptycho_handle h, double* state, void* prb, const void* dprb, void* stream) {
+    int rc = check_stage(h, state);
+    if (rc) return rc;
+    if (!prb || !dprb) return fail(PTYCHO_ERR_ARG, "null operand");
+    hipStream_t st = (hipStream_t)stream;
+    const long long np = (long long)h->ge.ptheta * h->ge.nprb * h->ge.nprb;
+    hipLaunchKernelGGL(k_cg_axpy, dim3(small_grid(h, np)), dim3(256), 0, st, (c32*)prb, (const c32*)dprb, np,
+                       (const double*)(state + PTYCHO_ST_GAMMA_PRB));
+    HIP_TRY(hipGetLastError());
+    return PTYCHO_OK;
+}
+
+}  // extern "C"

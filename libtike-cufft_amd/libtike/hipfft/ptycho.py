@@ -81,7 +81,8 @@ class PtychoHIP:
     ----------
     nscan : int   scan positions per angular view
     nprb : int    probe is ``nprb x nprb``
-    ndet : int    detector is ``ndet x ndet`` (power of two, 16..2048)
+    ndet : int    detector is ``ndet x ndet`` (2..1024, or a power of two up to 2048; powers of two
+                  run the fused kernels, other sizes a Bluestein transform)
     ptheta : int  angular views processed per call
     n, nz : int   object width, height
     """
@@ -449,7 +450,8 @@ def _zoom_shifts_native(op, image_product, best, upsample_factor):
     of ``ptycho.py:209-235``, or ``None`` if the kernels do not cover this case."""
     nb, nrow, ncol = image_product.shape
     region = int(np.ceil(upsample_factor * 1.5))
-    if (op is None or nrow != ncol or nrow != op.ndet or nb != op.ptheta * op.nscan
+    if (op is None or getattr(op, "_h", None) is None or not image_product.is_cuda
+            or nrow != ncol or nrow != op.ndet or nb != op.ptheta * op.nscan
             or nrow % 16 or nrow > 1024 or region > max(256, nrow) or upsample_factor < 1
             or image_product.dtype != torch.complex64 or not image_product.is_contiguous()):
         return None
@@ -494,10 +496,16 @@ def _finish_registration(image_product, maxima, upsample_factor, op=None):
     return shifts
 
 
-def register_translation_batch(op, src_image, target_image, upsample_factor=1,
-                               space="real"):
-    """Batched sub-pixel registration by phase cross-correlation
-    (``ptycho.py:190-248``).  ``op`` supplies the 2-D DFT (own HIP FFT)."""
+def register_translation_batch(src_image, target_image, upsample_factor=1,
+                               space="real", op=None):
+    """Batched sub-pixel registration by phase cross-correlation (``ptycho.py:190-248``, same
+    positional signature).  ``op``: an operator whose ``fft2`` (own HIP FFT) and fused zoom kernel
+    are used; without one a temporary handle for the image size is made."""
+    if op is None:
+        nb, ny, nx = src_image.shape
+        assert ny == nx, "square images only (the detector is square, ptychofft.cuh:31)"
+        with PtychoHIP(nb, nx, nx, 1, nx + 2, nx + 2) as tmp:
+            return register_translation_batch(src_image, target_image, upsample_factor, space, op=tmp)
     if space.lower() == "fourier":
         src_freq, target_freq = src_image, target_image
     elif space.lower() == "real":
@@ -507,7 +515,7 @@ def register_translation_batch(op, src_image, target_image, upsample_factor=1,
     image_product = src_freq * target_freq.conj()
     cross = op.fft2(image_product, inverse=True) / float(shape[1] * shape[2])
     maxima = _argmax2d(torch.abs(cross))
-    return _finish_registration(image_product, maxima, upsample_factor)
+    return _finish_registration(image_product, maxima, upsample_factor, op=op)
 
 
 # ---------------------------------------------------------------------------
@@ -528,7 +536,9 @@ class CGPtychoSolver(PtychoHIP):
         self.history = []      # (iteration, gammapsi, gammaprb, cost) per logged iteration
         self.verbose = True
         self.log_every = 32    # the reference prints every 32 iterations (ptycho.py:475)
-        self.fused = True      # single-mode gaussian loop through the fused CG-stage kernels
+        self.fused = True      # gaussian loops through the fused CG-stage kernels
+        self.native = True     # single-mode loop sequenced by the native stage calls (no host round trips)
+        self._nscan_all = None
 
     # -- distributed glue ----------------------------------------------------
     def _allreduce(self, t):
@@ -541,12 +551,16 @@ class CGPtychoSolver(PtychoHIP):
         return t
 
     def _nscan_total(self):
+        """Positions over all ranks (ptycho.py:431 divides the probe gradient by nscan); one collective
+        per solver, not per run."""
         if self.group is None:
             return self.nscan
-        import torch.distributed as dist
-        t = torch.tensor([float(self.nscan)], device=self._device)
-        dist.all_reduce(t, group=self.group)
-        return int(t.item())
+        if getattr(self, "_nscan_all", None) is None:
+            import torch.distributed as dist
+            t = torch.tensor([float(self.nscan)], device=self._device)
+            dist.all_reduce(t, group=self.group)
+            self._nscan_all = int(t.item())
+        return self._nscan_all
 
     @staticmethod
     def line_search_sqr(f, p1, p2, p3, step_length=1, step_shrink=0.5):
@@ -577,7 +591,7 @@ class CGPtychoSolver(PtychoHIP):
         if not (self.fused and self.ptheta == 1):
             tmp1 = self.fwd(psi, scan, ones)[0]
             tmp2 = self.fwd(psi + gammapsi * dpsi, scan, ones)[0]
-            return register_translation_batch(self, tmp1, tmp2, upsample_factor=100, space="fourier")
+            return register_translation_batch(tmp1, tmp2, upsample_factor=100, space="fourier", op=self)
         self._cg_fwd_cols(0, psi, scan, ones)
         self._cg_fwd_cols(1, dpsi, scan, ones)
         ip = torch.empty((self.nscan, self.ndet, self.ndet), dtype=torch.complex64, device=psi.device)
@@ -625,6 +639,94 @@ class CGPtychoSolver(PtychoHIP):
             gamma0 = step
             tried += ncand
             ncand = 16
+
+    # -- single-mode gaussian loop, sequenced natively ---------------------------------------
+    def _native_ready(self):
+        """The native stage calls cover one probe mode, ptheta = 1 (position correction) and detector
+        sizes the fused zoom kernel accepts."""
+        if not (self.native and self.ptheta == 1 and self.ndet % 16 == 0 and self.ndet <= 1024):
+            return None
+        return _zoom_real_factors(self.ndet, 150, 100, self._device)
+
+    def _run_native(self, data, psi, scan, probe, piter, recover_prb, zoom):
+        """``CGPtychoSolver.run`` (ptycho.py:283-488), one probe mode, gaussian model.  Same kernels and
+        the same arithmetic as ``_run_fused``, but every scalar of the iteration (a, b, the Dai-Yuan
+        sums, the line-search costs, the accepted step lengths) stays in a float64 state vector on the
+        device and the line search is decided there (C ABI ``ptycho_cg_obj_* / prb_* / ls_next``): an
+        iteration is ~13 library calls and no device synchronisation; the host reads the state back only
+        when it logs (every ``log_every`` iterations, as the reference prints every 32).  With a process
+        group the three scalar messages of a search and the two gradients are all-reduced in between."""
+        dev = data.device
+        data = self._operand(data, torch.float32, (self.ptheta, self.nscan, self.ndet, self.ndet), "data")
+        psi = self._operand(psi, torch.complex64, (self.ptheta, self.nz, self.n), "psi").clone()
+        self._operand(scan, torch.float32, (self.ptheta, self.nscan, 2), "scan")
+        assert probe.dtype == torch.complex64 and probe.is_contiguous() and scan.is_contiguous()
+        vt, lz, nc = zoom
+        st = self.__dict__.get("_cg_state")
+        if st is None or st.device != dev:
+            st = self._cg_state = torch.zeros(nat.ST_WORDS, dtype=torch.float64, device=dev)
+            st[nat.ST_HINT:nat.ST_HINT + 2] = 14.0
+        h, S = self._h, _stream()
+        sp, costs = _ptr(st), st[nat.ST_COSTS:nat.ST_COSTS + nat.ST_NCOSTS]
+        ones = self.__dict__.get("_ones_probe")
+        if ones is None or ones.shape != probe[:, 0].shape or ones.device != dev:
+            ones = self._ones_probe = torch.ones_like(probe[:, 0])
+        grad, grad0, dpsi = torch.empty_like(psi), torch.zeros_like(psi), torch.zeros_like(psi)
+        if recover_prb:
+            gprb, gprb0, dprb = (torch.zeros_like(probe[:, 0]) for _ in range(3))
+        nscan_total = float(self._nscan_total())
+        dist_on = self.group is not None
+
+        def line_search(which, use_ab):
+            for p in (1, 2, 3):
+                if dist_on:
+                    self._allreduce(costs)
+                nat.check(nat.cg_ls_next(h, sp, which, p, _ptr(data), use_ab, S))
+
+        if self.verbose:
+            print("# congujate gradient parameters\n"
+                  "iteration, step size object, step size probe, function min")
+        for i in range(piter):
+            # 1) object step (ptycho.py:325-405)
+            nat.check(nat.cg_obj_begin(h, sp, _ptr(psi), _ptr(scan), _ptr(probe), _ptr(data), S))
+            if dist_on:
+                self._allreduce(st[nat.ST_A:nat.ST_A + 2])
+            nat.check(nat.cg_obj_grad(h, sp, _ptr(scan), _ptr(probe), _ptr(data), _ptr(grad), S))
+            if dist_on:
+                self._allreduce(grad)
+            nat.check(nat.cg_obj_dir(h, sp, int(i == 0), _ptr(scan), _ptr(probe), _ptr(data), _ptr(grad),
+                                     _ptr(grad0), _ptr(dpsi), S))
+            line_search(0, 1)
+            nat.check(nat.cg_obj_finish(h, sp, int(i > 0), _ptr(psi), _ptr(dpsi), _ptr(scan), _ptr(ones),
+                                        _ptr(vt), _ptr(lz), nc, 150, 100.0, S))
+            # 2) probe step (ptycho.py:409-465)
+            if recover_prb:
+                nat.check(nat.cg_prb_grad(h, sp, _ptr(psi), _ptr(scan), _ptr(probe), _ptr(data), _ptr(gprb), S))
+                if dist_on:
+                    self._allreduce(gprb)
+                nat.check(nat.cg_prb_dir(h, sp, int(i == 0), nscan_total, 1.0, _ptr(psi), _ptr(scan), _ptr(data),
+                                         _ptr(gprb), _ptr(gprb0), _ptr(dprb), S))
+                line_search(1, 0)
+                nat.check(nat.cg_prb_finish(h, sp, _ptr(probe), _ptr(dprb), S))
+            if i % self.log_every == 0:
+                snap = st[:nat.ST_LS_FAILED + 1].clone()
+                if dist_on:
+                    self._allreduce(snap[nat.ST_COST:nat.ST_COST + 1])
+                snap = snap.cpu()
+                self.history.append((i, float(snap[nat.ST_GAMMA_PSI]), float(snap[nat.ST_GAMMA_PRB]),
+                                     float(snap[nat.ST_COST].to(torch.float32))))
+                if self.verbose:
+                    print("%4d, %.3e, %.3e, %.7e" % self.history[-1])
+        failed = int(st[nat.ST_LS_FAILED].item())
+        if failed:
+            st[nat.ST_LS_FAILED] = 0.0
+            for _ in range(failed):
+                warnings.warn("Line search failed for conjugate gradient.")
+        # the native loop moved scan behind torch's back: forget what the operator calls knew about it
+        self._scan_key = None
+        self._scan_trusted = None
+        nat.check(nat.set_option(self._h, b"trust_order", 0))
+        return {"psi": psi, "probe": probe}
 
     def _run_fused(self, data, psi, scan, probe, piter, recover_prb):
         """``CGPtychoSolver.run`` (ptycho.py:283-488) for one probe mode and the gaussian
@@ -840,8 +942,12 @@ class CGPtychoSolver(PtychoHIP):
         """
         assert probe.ndim == 4, "probe needs 4 dimensions, not %d" % probe.ndim
         nmodes = probe.shape[1]
-        if self.fused and model == "gaussian":
+        pow2 = self.ndet >= 16 and (self.ndet & (self.ndet - 1)) == 0   # the fused CG stages use the power-of-two plans
+        if self.fused and model == "gaussian" and pow2:
             if nmodes == 1:
+                zoom = self._native_ready()
+                if zoom is not None:
+                    return self._run_native(data, psi, scan, probe, piter, recover_prb, zoom)
                 return self._run_fused(data, psi, scan, probe, piter, recover_prb)
             if nmodes <= 8:          # one pair of work slots per mode (ptycho_hip.h)
                 return self._run_fused_multi(data, psi, scan, probe, piter, recover_prb)
@@ -909,8 +1015,8 @@ class CGPtychoSolver(PtychoHIP):
                 ones = probe[:, 0] * 0 + 1
                 tmp1 = self.fwd(psi, scan, ones)[0]
                 tmp2 = self.fwd(psi + gammapsi * dpsi, scan, ones)[0]
-                shifts = register_translation_batch(self, tmp1, tmp2, upsample_factor=100,
-                                                    space="fourier")
+                shifts = register_translation_batch(tmp1, tmp2, upsample_factor=100,
+                                                    space="fourier", op=self)
                 scan[0, :] += shifts.to(scan.dtype)
             psi = psi + gammapsi * dpsi
 

@@ -170,9 +170,10 @@ def test_registration_recovers_known_shift(pt):
     moved = np.stack([f[i] * np.exp(-2j * np.pi * (ky * true[i, 0] + kx * true[i, 1])) for i in range(3)])
     want = cg.register_translation_batch(f.astype(np.complex64), moved.astype(np.complex64), 100, "fourier")
     with pt.PtychoCuFFT(3, 32, 32, 1, 64, 64) as slv:
-        got = register_translation_batch(slv, torch.as_tensor(f.astype(np.complex64), device="cuda"),
-                                         torch.as_tensor(moved.astype(np.complex64), device="cuda"),
-                                         100, "fourier").cpu().numpy()
+        a, b = (torch.as_tensor(z.astype(np.complex64), device="cuda") for z in (f, moved))
+        got = register_translation_batch(a, b, 100, "fourier", op=slv).cpu().numpy()
+        # the reference's positional signature (ptycho.py:190), without an operator: a temporary handle
+        np.testing.assert_array_equal(register_translation_batch(a, b, 100, "fourier").cpu().numpy(), got)
     np.testing.assert_allclose(got, -true, atol=0.011)
     np.testing.assert_allclose(got, want, atol=0.011)
 
@@ -213,3 +214,22 @@ def test_zoom_kernel_matches_torch_contraction(ndet):
         np.testing.assert_allclose(P._finish_registration(dip, dmax, 100).cpu().numpy(), want, rtol=0, atol=1e-13)
         np.testing.assert_array_equal(P._finish_registration(dip, dmax, 100, op=slv).cpu().numpy(), want)
         assert np.abs(got.cpu().numpy() - true).max() < 0.02
+
+
+def test_cg_at_a_cropped_detector_size(pt):
+    """ndet = nprb = 112 (tests/test_fsc.py:115-120): the solver runs the statement-by-statement loop on the
+    Bluestein operators and tracks the oracle."""
+    ndet = 112
+    p = syn.make_problem(4, 4, 9, ndet, ndet, seed=21)
+    rng = np.random.default_rng(9)
+    probe = (p["probe"][:, None] * np.exp(2j * np.pi * rng.random((ndet, ndet)))).astype(np.complex64)
+    ora = cg.OracleSolver(p["nscan"], ndet, ndet, 1, p["nz"], p["n"])
+    data = (np.abs(ora.fwd(p["psi"], p["scan"], probe[:, 0])) ** 2).astype(np.float32)
+    want = ora.run(data.copy(), np.ones_like(p["psi"]), p["scan"].copy(), probe.copy(), piter=4)
+    with pt.CGPtychoSolver(p["nscan"], ndet, ndet, 1, p["nz"], p["n"]) as slv:
+        slv.verbose, slv.log_every = False, 1
+        got = slv.run_batch(data.copy(), np.ones_like(p["psi"]), p["scan"].copy(), probe.copy(), piter=4)
+        hist = list(slv.history)
+    for (i, gp, gq, c), (io, gpo, gqo, co) in zip(hist, ora.history):
+        assert (i, gp, gq) == (io, gpo, gqo) and abs(c - co) <= 1e-4 * abs(co)
+    assert np.abs(got["psi"] - want["psi"]).max() < 2e-4 * np.abs(want["psi"]).max()

@@ -299,7 +299,7 @@ def test_error_behaviour(pt):
     import torch
     from libtike.hipfft import _native as nat
     with pytest.raises(nat.PtychoHipError):
-        pt.PtychoCuFFT(4, 16, 48, 1, 64, 64)          # ndet not a power of two
+        pt.PtychoCuFFT(4, 16, 1100, 1, 1200, 1200)    # ndet neither <= 1024 nor a power of two
     with pytest.raises(nat.PtychoHipError):
         pt.PtychoCuFFT(4, 32, 16, 1, 64, 64)          # nprb > ndet
     slv = pt.PtychoCuFFT(4, 16, 16, 1, 64, 64)
@@ -317,3 +317,42 @@ def test_error_behaviour(pt):
         slv.fwd(psi, scan, prb)
     with pytest.raises(NotImplementedError):
         pt.PtychoCuFFT(4, 16, 16, 1, 64, 64).run(None, None, None, None)
+
+
+# ---- detector sizes that are not a power of two (cuFFT takes any size, ptychofft.cu:13-20) ----------------
+@pytest.mark.parametrize("ndet", [12, 30, 96, 100, 112, 200, 1000])
+def test_fft2_any_size_matches_numpy(pt, ndet):
+    rng = np.random.default_rng(ndet)
+    nb = 3 if ndet < 500 else 2
+    x = (rng.standard_normal((nb, ndet, ndet)) + 1j * rng.standard_normal((nb, ndet, ndet))).astype(np.complex64)
+    with pt.PtychoCuFFT(nb, ndet, ndet, 1, ndet + 2, ndet + 2) as slv:
+        got = host(slv.fft2(dev(x)))
+        back = host(slv.fft2(dev(x), inverse=True))
+    want = np.fft.fft2(x.astype(np.complex128))
+    assert np.abs(got - want).max() <= 2e-6 * np.abs(want).max()
+    wantb = np.fft.ifft2(x.astype(np.complex128)) * ndet * ndet          # unnormalised, like cufftExecC2C INVERSE
+    assert np.abs(back - wantb).max() <= 2e-6 * np.abs(wantb).max()
+
+
+@pytest.mark.parametrize("ndet,nprb,ntheta", [(112, 112, 1), (100, 64, 2), (30, 17, 1)])
+def test_operators_any_detector_size_match_oracle(pt, ndet, nprb, ntheta):
+    """/root/reference/tests/test_fsc.py:115-120 crops the detector and the probe from 128 to 112:
+    fwd / adj / adj_probe at such sizes against the oracle, and the adjoint identity."""
+    p = syn.make_problem(4, 5, 7, nprb, ndet, ntheta=ntheta, seed=ndet)
+    rng = np.random.default_rng(1)
+    scan = p["scan"].copy()
+    scan[0, 0] = (-0.5, 1.0) if ndet == 100 else scan[0, 0]   # -0.0 integer part: NOT skipped, negative fraction (kernels.cu:39)
+    prb = (p["probe"] * np.exp(2j * np.pi * rng.random((nprb, nprb)))).astype(np.complex64)
+    y = (rng.standard_normal((ntheta, p["nscan"], ndet, ndet)) + 1j * rng.standard_normal((ntheta, p["nscan"], ndet, ndet))).astype(np.complex64)
+    with pt.PtychoCuFFT(p["nscan"], nprb, ndet, ntheta, p["nz"], p["n"]) as slv:
+        g = host(slv.fwd(dev(p["psi"]), dev(scan), dev(prb)))
+        a = host(slv.adj(dev(y), dev(scan), dev(prb)))
+        b = host(slv.adj_probe(dev(y), dev(scan), dev(p["psi"])))
+    for got, want in ((g, op.fwd(p["psi"], scan, prb, ndet, "double")),
+                      (a, op.adj(y, scan, prb, p["nz"], p["n"], "double")),
+                      (b, op.adj_probe(y, scan, p["psi"], nprb, "double"))):
+        assert np.abs(got - want).max() <= REL_MAX * np.abs(want).max()
+    lhs = np.vdot(y.astype(np.complex128), g.astype(np.complex128))
+    r1 = np.vdot(a.astype(np.complex128), p["psi"].astype(np.complex128))
+    r2 = np.vdot(b.astype(np.complex128), prb.astype(np.complex128))
+    assert abs(lhs - r1) < 1e-5 * abs(lhs) and abs(lhs - r2) < 1e-5 * abs(lhs)

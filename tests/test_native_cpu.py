@@ -45,8 +45,8 @@ def test_code_object_targets_gfx950(nat):
 
 def test_argument_validation_needs_no_gpu(nat):
     h = ctypes.c_void_p()
-    # ndet = 48: not a power of two
-    assert nat.create(ctypes.byref(h), 1, 64, 64, 4, 48, 16) == 1
+    # ndet = 1100: neither <= 1024 (Bluestein path) nor a power of two
+    assert nat.create(ctypes.byref(h), 1, 1200, 1200, 4, 1100, 16) == 1
     assert b"power of two" in nat.last_error()
     assert nat.create(ctypes.byref(h), 1, 64, 64, 4, 16, 32) == 1      # nprb > ndet
     assert nat.create(ctypes.byref(h), 0, 64, 64, 4, 16, 16) == 1      # zero size

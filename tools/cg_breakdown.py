@@ -25,7 +25,7 @@ print("p1p2p3 ms", T(lambda: (torch.abs(g)**2, torch.abs(g2)**2, 2*(g.real*g2.re
 p1,p2,p3 = torch.abs(g)**2, torch.abs(g2)**2, 2*(g.real*g2.real+g.imag*g2.imag)
 minf = lambda x: torch.sum((torch.sqrt(torch.abs(x))-torch.sqrt(data))**2)
 print("one line-search trial ms", T(lambda: float(minf(p1+0.25*p2+0.5*p3))))
-print("registration ms", T(lambda: register_translation_batch(slv, g[0], g2[0], 100, 'fourier'), 2))
+print("registration ms", T(lambda: register_translation_batch(g[0], g2[0], 100, 'fourier', op=slv), 2))
 print("fft2 ms", T(lambda: slv.fft2(g[0], inverse=True)))
 t=time.perf_counter(); slv.run(data, torch.ones_like(psi), scan.clone(), prb[:,None].clone(), piter=4); torch.cuda.synchronize()
 print("4 iters ms/iter", (time.perf_counter()-t)/4*1e3)
