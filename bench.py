@@ -50,7 +50,58 @@ def parse():
     ap.add_argument("--cpu-sample", type=int, default=192)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-cg", action="store_true")
+    ap.add_argument("--no-cfg3", action="store_true", help="skip the configs[2] secondary figures (4096 x 512^2, 4 modes)")
+    ap.add_argument("--cfg3-iters", type=int, default=6)
     return ap.parse_args()
+
+
+def cfg3_figures(pt, syn, dev, iters):
+    """Secondary figures on BASELINE.json configs[2]: 4096 positions x (512 x 512), 4 probe modes
+    (Gaussian x Hermite, SURVEY.md 8d cfg 3), object 1024^2: fwd+adj pair of one mode, its roofline
+    fraction, multi-mode CG iterations/s and the device memory the solver holds."""
+    R, step, ndet, M = 64, 8, 512, 4
+    nz = n = 1024
+    rng = np.random.default_rng(4321)
+    psi = torch.as_tensor(syn.random_object(nz, n, rng), device=dev)
+    scan = torch.as_tensor(syn.raster_scan(R, R, step, rng), device=dev)
+    modes = torch.as_tensor(syn.hermite_modes(ndet, M), device=dev)
+    torch.cuda.synchronize()
+    torch.cuda.reset_peak_memory_stats()
+    free0, _ = torch.cuda.mem_get_info()
+    slv = pt.CGPtychoSolver(R * R, ndet, ndet, 1, nz, n)
+    slv.verbose = False
+    prb0 = modes[:, 0].contiguous()
+    g = slv.fwd(psi, scan, prb0)
+    slv.adj(g, scan, prb0)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        g = slv.fwd(psi, scan, prb0)
+        slv.adj(g, scan, prb0)
+    torch.cuda.synchronize()
+    pair_ms = (time.perf_counter() - t0) / 5 * 1e3
+    data = torch.zeros((1, R * R, ndet, ndet), dtype=torch.float32, device=dev)
+    for k in range(M):
+        g = slv.fwd(psi, scan, modes[:, k].contiguous())
+        data += torch.abs(g) ** 2
+    del g
+    torch.cuda.empty_cache()
+    slv.run(data, torch.ones_like(psi), scan.clone(), modes.clone(), piter=2)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    slv.run(data, torch.ones_like(psi), scan.clone(), modes.clone(), piter=iters)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / iters
+    free1, _ = torch.cuda.mem_get_info()
+    pair_bytes = 2.0 * (8.0 * R * R * ndet * ndet + 8.0 * nz * n + 8.0 * ndet * ndet + 8.0 * R * R)
+    slv.free()
+    return {"cfg3_workload": "4096 positions x (512x512), 4 probe modes, object 1024x1024 (BASELINE.json configs[2])",
+            "cfg3_pair_ms": pair_ms, "cfg3_patterns_per_s": R * R / (pair_ms * 1e-3),
+            "cfg3_roofline_frac": pair_bytes / (pair_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "cfg3_cg_it_s": 1.0 / dt, "cfg3_cg_ms_per_iteration": dt * 1e3, "cfg3_cg_iters_timed": iters,
+            "cfg3_device_gib_in_use": (free0 - free1) / 2.0 ** 30,
+            "cfg3_note": "CG: 4 modes, no probe recovery, position correction on; memory = device memory taken between "
+                         "solver creation and the end of the run (work slots, scratch, intensity, registration, data 4 GiB)"}
 
 
 def cpu_baseline(args, prob):
@@ -254,8 +305,8 @@ def main():
                 data = None
         cg = {"cg_iterations_per_s": args.cg_iters / dt, "cg_iters_timed": args.cg_iters,
               "cg_ms_per_iteration": dt / args.cg_iters * 1e3,
-              "cg_config": "gaussian, 1 mode, no probe recovery, position correction on (reference loop), "
-                           "initial object = 1, timed from iteration 0"
+              "cg_config": "gaussian, 1 mode, no probe recovery, position correction on (reference loop, sequenced by "
+                           "the native stage calls), initial object = 1, timed from iteration 0"
                            + (" (weak: %d positions per GPU)" % nscan if ngpu > 1 else "")}
         if strong:
             cg.update(strong)
@@ -282,6 +333,13 @@ def main():
     elif rank == 0:
         out["cpu_baseline"] = None
     slv.free()
+    if ngpu == 1 and not dist and not args.no_cfg3 and not args.no_cg:
+        try:
+            del psi, scan, prb
+            torch.cuda.empty_cache()
+            out.update(cfg3_figures(pt, syn, dev, args.cfg3_iters))
+        except Exception as e:          # never let a secondary figure break the primary line
+            print("configs[2] figures failed: %r" % (e,), file=sys.stderr)
     if dist:
         dist.barrier()
         dist.destroy_process_group()

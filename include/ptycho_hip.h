@@ -118,6 +118,22 @@ int ptycho_cg_linesearch_modes(ptycho_handle h, int mode0, int nmodes, const voi
                                const double* ab, double gamma0, int ncand, double* costs,
                                void* stream);
 
+/* Compact multi-mode layout (option "compact_modes" = M): mode k keeps its forward column pass in slot k and ALL
+ * modes share one further slot M (projected residual of one mode at a time; direction column passes), M + 1
+ * farplanes instead of 2 M.  The object line search (ptycho.py:383-393) needs fwd(dpsi, probe_k) of every mode at
+ * once, so it runs over M equal ranges ("chunks") of positions: for chunk c the M direction column passes of
+ * those positions go side by side into the shared slot and one line-search pass adds the chunk's costs -- the
+ * same work as before in M smaller launches.  The option also makes the position order chunk-major.
+ *   ptycho_cg_fwd_cols_modes   column passes of fwd(f, scan, prbs[k]) for nmodes modes (mode0 ...), the object
+ *                              patch gathered once per position for up to four modes per launch (ptycho.py:330-333
+ *                              gathers per mode); into_b = 0: into the modes' own slots, all positions;
+ *                              into_b = 1 (compact layout, all modes): the positions of `chunk` into the shared slot
+ *   ptycho_cg_linesearch_chunk costs += line-search costs of chunk `chunk` (pairs: slot k, shared slot part k) */
+int ptycho_cg_fwd_cols_modes(ptycho_handle h, int nmodes, int mode0, const void* f, const void* scan,
+                             const void* const* prbs, int into_b, int chunk, void* stream);
+int ptycho_cg_linesearch_chunk(ptycho_handle h, int chunk, const void* data, const double* ab, double gamma0,
+                               int ncand, double* costs, void* stream);
+
 /* Position correction (ptycho.py:398-403 + 198-207), fused: with the column passes of
  * fwd(psi, 1) in slot1 and fwd(dpsi, 1) in slot2,
  *   ptycho_cg_cross   image_product = u1 conj(u2), u2 = u1 + gamma G dpsi (complex64
@@ -159,10 +175,10 @@ int ptycho_cg_zoom(ptycho_handle h, const void* image_product, const void* best,
  *                         grad <- adj (raw, not yet divided by max|probe|^2).   all-reduce: grad
  *   ptycho_cg_obj_dir     grad /= max|probe|^2 (:356); Dai-Yuan dpsi, grad0 <- grad (:366-373); slot 1 <- column
  *                         pass of fwd(dpsi, probe); first line-search pass (:383-393).
- *                                                                    all-reduce: state[PTYCHO_ST_COSTS .. +102)
- *   ptycho_cg_ls_next     decide on the pass just reduced (line_search_sqr, :253-281); pass = 1, 2: issue the next
- *                         pass (16, then 96 step lengths; each returns at once when the search is already
- *                         resolved) -> all-reduce state[COSTS..] again; pass = 3: decide only.  The accepted
+ *                                                                    all-reduce: state[PTYCHO_ST_COSTS .. +68)
+ *   ptycho_cg_ls_next     decide on the pass just reduced (line_search_sqr, :253-281); pass = 1, 2, 3: issue the next
+ *                         pass (16, 32, 64 step lengths; each returns at once when the search is already
+ *                         resolved) -> all-reduce state[COSTS..] again; pass = 4: decide only.  The accepted
  *                         step length times 0.5 lands in state[GAMMA_PSI] (which = 0) / state[GAMMA_PRB] (which = 1).
  *   ptycho_cg_obj_finish  i > 0: position correction (:398-403; needs the zoom factors of ptycho_cg_zoom), scan[0] += shifts;
  *                         psi += gamma dpsi (:405)
@@ -182,7 +198,7 @@ enum {
     PTYCHO_ST_LS_GAMMA0 = 14, PTYCHO_ST_LS_NCAND = 15, PTYCHO_ST_LS_NGROUPS = 16, PTYCHO_ST_LS_TRIED = 17,
     PTYCHO_ST_LS_RESOLVED = 18, PTYCHO_ST_LS_FAILED = 19,
     PTYCHO_ST_HINT = 20,                        /* [2] accepted index of the last object / probe search (seed with 14) */
-    PTYCHO_ST_COSTS = 24,                       /* 6 groups x (16 step lengths + f(p1)) */
+    PTYCHO_ST_COSTS = 24,                       /* 4 groups x (16 step lengths + f(p1)) */
     PTYCHO_CG_STATE_WORDS = 128
 };
 int ptycho_cg_obj_begin(ptycho_handle h, double* state, const void* psi, const void* scan, const void* prb,
@@ -207,6 +223,10 @@ int ptycho_cg_prb_finish(ptycho_handle h, double* state, void* prb, const void* 
  * same pointer with unchanged contents as in the previous call, so the position sort is
  * reused; set 0 after modifying scan; default 0);
  * "split" (ndet = 256: 1 = one radix-16 step of the DFT over y runs in the row pass [default]);
+ * "deterministic" (1 = the adjoints add their per-workgroup sums into a 64-bit fixed-point image with integer
+ * atomics and fold it into the output once: bitwise reproducible for a given chunk / run partition, one extra read of
+ * g for the scale; needs the windowed kernels, ndet <= 512; default 0: float atomics, as kernels.cu:73-80,92-93);
+ * "compact_modes" (M = number of probe modes: compact slot layout + chunk-major position order, see above; 0 = slot pairs);
  * "fused" (ndet = 256: forward operator as ONE launch that keeps the column<->row intermediate on
  * the CU, k_fwd_fused256: 0 = off, 1 / 2 = one / two class tiles per pass).
  * Environment variables read at handle creation / first launch, for experiments only:

@@ -14,7 +14,7 @@
 //   k_cg_add_shifts    scan[0] += shifts                                           (ptycho.py:403)
 #pragma once
 
-constexpr int kLsGroupsMax = 6;   // a line-search pass prices up to 6 groups of 16 step lengths
+constexpr int kLsGroupsMax = 4;   // a line-search pass prices up to 4 groups of 16 step lengths
 
 __global__ void k_cg_scale_probe(c32* __restrict__ prb, const long long n, const double* __restrict__ st) {
     const float s = (float)st[PTYCHO_ST_A] / (float)st[PTYCHO_ST_B];   // float32, as ptycho.py:344 computes it
@@ -159,7 +159,7 @@ __global__ void k_cg_ls_decide(double* __restrict__ st, const int which, const i
         }
         if (!done) tried += ncand;
     }
-    if (!done && next_ngroups == 0) {   // cannot happen with 2..16 + 16 + 96 step lengths (2^-106 < 1e-32); fail safe
+    if (!done && next_ngroups == 0) {   // cannot happen with 2..16 + 16 + 32 + 64 step lengths (2^-106 < 1e-32); fail safe
         st[gamma_word] = 0.0;
         st[PTYCHO_ST_LS_FAILED] += 1.0;
         done = true;
@@ -170,4 +170,31 @@ __global__ void k_cg_ls_decide(double* __restrict__ st, const int which, const i
     st[PTYCHO_ST_LS_NCAND] = (double)kMaxCand;
     st[PTYCHO_ST_LS_NGROUPS] = (double)next_ngroups;
     for (int i = 0; i < kLsGroupsMax * (kMaxCand + 1); ++i) st[PTYCHO_ST_COSTS + i] = 0.0;
+}
+
+// ---- deterministic adjoints: fixed-point accumulation (ColArgs::det_acc) ----------------------------
+// scale = 2^e with  2^e * bound < 2^52,  bound = max|g| * max|prb or psi| * ndet >= any single window sum / probe sum
+// contribution's magnitude (|near| <= ndet^2 max|g|, times c = 1/ndet, times |prb|): ten more bits of the 63 are
+// headroom for the sum over overlapping positions.  words: float bits of max|g| and max|other| (k_cg_absmax).
+__global__ void k_det_scale(const double* __restrict__ word_g, const double* __restrict__ word_o, const int ndet, const long long nadd,
+                            float* __restrict__ scale) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const float bound = absmax_of(word_g) * absmax_of(word_o) * (float)ndet;
+    int e = 0;
+    frexpf(bound > 0.0f ? bound : 1.0f, &e);              // bound < 2^e
+    int head = 1;
+    while ((1ll << head) < nadd && head < 30) ++head;   // additions per element
+    int p = 62 - head - e;
+    p = p > 120 ? 120 : (p < -120 ? -120 : p);
+    *scale = ldexpf(1.0f, p);
+}
+__global__ void k_det_finish(c32* __restrict__ dst, long long* __restrict__ acc, const long long n, const float* __restrict__ scale) {
+    const double inv = 1.0 / (double)*scale;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const double re = (double)acc[2 * i] * inv, im = (double)acc[2 * i + 1] * inv;
+        acc[2 * i] = 0;
+        acc[2 * i + 1] = 0;
+        const c32 v = dst[i];
+        dst[i] = c32{v.x + (float)re, v.y + (float)im};
+    }
 }

@@ -72,9 +72,16 @@ __global__ __launch_bounds__(ColCfg<N>::NT) void k_cols_adjwin(const ColArgs a, 
             win[slot] = zero;
             const int X = X0 + col;
             if ((v.x != 0.0f || v.y != 0.0f) && Y < ge.nz && X >= 0 && X < ge.n) {
-                float* op = reinterpret_cast<float*>(fo + (size_t)Y * ge.n + X);
-                atomicAdd(op, v.x);
-                atomicAdd(op + 1, v.y);
+                const size_t e = ((size_t)t_w * ge.nz + Y) * ge.n + X;
+                if (a.det_acc) {
+                    const float sc = *a.det_scale;
+                    atomicAdd(reinterpret_cast<unsigned long long*>(a.det_acc + 2 * e), (unsigned long long)__float2ll_rn(v.x * sc));
+                    atomicAdd(reinterpret_cast<unsigned long long*>(a.det_acc + 2 * e + 1), (unsigned long long)__float2ll_rn(v.y * sc));
+                } else {
+                    float* op = reinterpret_cast<float*>(a.dst + e);
+                    atomicAdd(op, v.x);
+                    atomicAdd(op + 1, v.y);
+                }
             }
         }
     };
@@ -238,10 +245,14 @@ __global__ __launch_bounds__(ColCfg<N>::NT) void k_cols_adjwin(const ColArgs a, 
 //   M_FWD     : v = (c*prb) * bilerp(window)  -> DFT over y -> strip of g
 //   M_ADJ_PRB : IDFT over y of the scratch strip; acc += near * conj(bilerp(window))
 // ---------------------------------------------------------------------------
-template <int N, int MODE, bool SPLIT = false>
+template <int N, int MODE, bool SPLIT = false, int NM = 1>
 __global__ __launch_bounds__(ColCfg<N>::NT) void k_cols_gatherwin(const ColArgs a, const int seglen) {
     // SPLIT (N = 256): only one radix-16 step of the DFT over y runs here (thread local, no
     // exchange buffer -> 44 KiB of LDS, three workgroups per CU); k_rows_split does the other.
+    // NM > 1 (forward only): NM probe modes per launch.  The bilinear patch values of a position are
+    // gathered from the window ONCE and multiplied by the NM probe strips (all in VGPRs), giving the
+    // strips of NM farplanes dstm[k] (ptycho.py:330-333 calls fwd once per mode and gathers each time).
+    static_assert(NM == 1 || (MODE == M_FWD && !SPLIT), "several probe modes: un-split forward pass only");
     using P = Plan<N>;
     constexpr int DIR = (MODE == M_FWD) ? -1 : +1;
     using F = Fft<P, DIR>;
@@ -269,7 +280,8 @@ __global__ __launch_bounds__(ColCfg<N>::NT) void k_cols_gatherwin(const ColArgs 
 
     // FWD: c * probe strip in step-0 slot order (zero on padding -> masks the gather);
     // ADJ_PRB: gradient accumulators in natural order m (row j0 + m*T)
-    c32 pr[E];
+    c32 prm[NM][E];
+    c32 (&pr)[E] = prm[0];
     int cur_t = -1;
     int t_w = -1, X0 = 0, Ylo = 0, Yhi = 0;   // cached object rows [Ylo, Yhi), columns [X0, X0+WC)
 
@@ -278,10 +290,17 @@ __global__ __launch_bounds__(ColCfg<N>::NT) void k_cols_gatherwin(const ColArgs 
         for (int m = 0; m < E; ++m) {
             const int iy = j0 + m * T - ge.pad;
             if (col_ok && iy >= 0 && iy < ge.nprb) {
-                float* o = reinterpret_cast<float*>(a.dst + ((size_t)t * ge.nprb + iy) * ge.nprb + ix);
+                const size_t e = ((size_t)t * ge.nprb + iy) * ge.nprb + ix;
                 const c32 sacc = pr[m] * cinv;
-                atomicAdd(o, sacc.x);
-                atomicAdd(o + 1, sacc.y);
+                if (a.det_acc) {
+                    const float sc = *a.det_scale;
+                    atomicAdd(reinterpret_cast<unsigned long long*>(a.det_acc + 2 * e), (unsigned long long)__float2ll_rn(sacc.x * sc));
+                    atomicAdd(reinterpret_cast<unsigned long long*>(a.det_acc + 2 * e + 1), (unsigned long long)__float2ll_rn(sacc.y * sc));
+                } else {
+                    float* o = reinterpret_cast<float*>(a.dst + e);
+                    atomicAdd(o, sacc.x);
+                    atomicAdd(o + 1, sacc.y);
+                }
             }
         }
     };
@@ -445,16 +464,19 @@ __global__ __launch_bounds__(ColCfg<N>::NT) void k_cols_gatherwin(const ColArgs 
     __syncthreads();
     for (int k = kb; k < ke; ++k) {
         if (MODE == M_FWD && st.t != cur_t) {
-            const c32* prb = a.aux + (size_t)st.t * ge.nprb * ge.nprb;
 #pragma unroll
-            for (int b = 0; b < E / R0; ++b)
+            for (int km = 0; km < NM; ++km) {
+                const c32* prb = (NM == 1 ? a.aux : a.auxm[km]) + (size_t)st.t * ge.nprb * ge.nprb;
 #pragma unroll
-                for (int tt = 0; tt < R0; ++tt) {
-                    const int iy = j0 + b * T + tt * (N / R0) - ge.pad;
-                    const bool ok = col_ok && iy >= 0 && iy < ge.nprb;
-                    const c32 w = prb[ok ? ((size_t)iy * ge.nprb + ix) : 0];
-                    pr[b * R0 + tt] = ok ? w * cinv : zero;
-                }
+                for (int b = 0; b < E / R0; ++b)
+#pragma unroll
+                    for (int tt = 0; tt < R0; ++tt) {
+                        const int iy = j0 + b * T + tt * (N / R0) - ge.pad;
+                        const bool ok = col_ok && iy >= 0 && iy < ge.nprb;
+                        const c32 w = prb[ok ? ((size_t)iy * ge.nprb + ix) : 0];
+                        prm[km][b * R0 + tt] = ok ? w * cinv : zero;
+                    }
+            }
             cur_t = st.t;
         }
         if (MODE == M_ADJ_PRB && st.q.valid && st.t != cur_t) {
@@ -465,9 +487,12 @@ __global__ __launch_bounds__(ColCfg<N>::NT) void k_cols_gatherwin(const ColArgs 
         }
         if (!st.q.valid) {
             if (MODE == M_FWD) {   // skipped position: exact zeros (memset of ptychofft.cu:69)
-                c32* tile_out = a.dst + (size_t)st.p * N * N;
 #pragma unroll
-                for (int m = 0; m < E; ++m) tile_out[(size_t)(j0 + m * T) * N + x] = zero;
+                for (int km = 0; km < NM; ++km) {
+                    c32* tile_out = (NM == 1 ? a.dst : a.dstm[km]) + (size_t)st.p * N * N;
+#pragma unroll
+                    for (int m = 0; m < E; ++m) tile_out[(size_t)(j0 + m * T) * N + x] = zero;
+                }
             }
             __syncthreads();
             st = prepare(k + 1, ke);
@@ -490,6 +515,7 @@ __global__ __launch_bounds__(ColCfg<N>::NT) void k_cols_gatherwin(const ColArgs 
         };
 
         c32 v[E];
+        c32 vbase[NM > 1 ? E : 1];   // patch values in step-0 slot order, shared by the NM modes
         if (MODE == M_FWD) {
             c32 nat[E];
             int slot = slot0;
@@ -500,6 +526,10 @@ __global__ __launch_bounds__(ColCfg<N>::NT) void k_cols_gatherwin(const ColArgs 
                 slot = slot >= H ? slot - H : slot;
             }
             F::from_natural(nat, v);
+            if (NM > 1) {
+#pragma unroll
+                for (int s2 = 0; s2 < E; ++s2) vbase[s2] = v[s2];
+            }
 #pragma unroll
             for (int s2 = 0; s2 < E; ++s2) v[s2] = cmul(pr[s2], v[s2]);
         } else {
@@ -519,32 +549,41 @@ __global__ __launch_bounds__(ColCfg<N>::NT) void k_cols_gatherwin(const ColArgs 
             st = nx;
             continue;
         }
-        if (P::NSTEP > 1) {
-            fft.template store<0>(v, j0, [&](int i, c32 val) { lds[i * C + c] = val; });
-            __syncthreads();
-            if (MODE == M_FWD) nx = prepare_issue(k + 1, ke);   // window of k is no longer read
-            fft.template load<1>(v, j0, [&](int i) { return lds[i * C + c]; });
-            if (P::NSTEP > 2) {
-                __syncthreads();
-                fft.template compute<1>(v);
-                fft.template store<1>(v, j0, [&](int i, c32 val) { lds[i * C + c] = val; });
-                __syncthreads();
-                fft.template load<2>(v, j0, [&](int i) { return lds[i * C + c]; });
+#pragma unroll
+        for (int km = 0; km < NM; ++km) {
+            if (km > 0) {   // next probe mode on the same patch values
+#pragma unroll
+                for (int s2 = 0; s2 < E; ++s2) v[s2] = cmul(prm[km][s2], vbase[s2]);
+                fft.template compute<0>(v);
             }
-            fft.template compute<LAST>(v);
-        } else if (MODE == M_FWD) {
-            __syncthreads();
-            nx = prepare_issue(k + 1, ke);
+            if (P::NSTEP > 1) {
+                fft.template store<0>(v, j0, [&](int i, c32 val) { lds[i * C + c] = val; });
+                __syncthreads();
+                if (MODE == M_FWD && km == 0) nx = prepare_issue(k + 1, ke);   // window of k is no longer read
+                fft.template load<1>(v, j0, [&](int i) { return lds[i * C + c]; });
+                if (P::NSTEP > 2) {
+                    __syncthreads();
+                    fft.template compute<1>(v);
+                    fft.template store<1>(v, j0, [&](int i, c32 val) { lds[i * C + c] = val; });
+                    __syncthreads();
+                    fft.template load<2>(v, j0, [&](int i) { return lds[i * C + c]; });
+                }
+                fft.template compute<LAST>(v);
+            } else if (MODE == M_FWD && km == 0) {
+                __syncthreads();
+                nx = prepare_issue(k + 1, ke);
+            }
+            if (MODE == M_FWD) {
+                c32* tile_out = (NM == 1 ? a.dst : a.dstm[km]) + (size_t)st.p * N * N;
+                if (a.nt & 4)
+                    fft.template store<LAST>(v, j0, [&](int i, c32 val) { __builtin_nontemporal_store(val, tile_out + (size_t)i * N + x); });
+                else
+                    fft.template store<LAST>(v, j0, [&](int i, c32 val) { tile_out[(size_t)i * N + x] = val; });
+                if (km == NM - 1) prepare_commit();
+                __syncthreads();   // exchange buffer / new window rows visible to everyone
+            }
         }
-        if (MODE == M_FWD) {
-            c32* tile_out = a.dst + (size_t)st.p * N * N;
-            if (a.nt & 4)
-                fft.template store<LAST>(v, j0, [&](int i, c32 val) { __builtin_nontemporal_store(val, tile_out + (size_t)i * N + x); });
-            else
-                fft.template store<LAST>(v, j0, [&](int i, c32 val) { tile_out[(size_t)i * N + x] = val; });
-            prepare_commit();
-            __syncthreads();   // exchange buffer / new window rows visible to everyone
-        } else {
+        if (MODE != M_FWD) {
             c32 nat[E];
             F::to_natural(v, nat);
             int slot = slot0;
@@ -576,31 +615,34 @@ __global__ __launch_bounds__(ColCfg<N>::NT) void k_cols_gatherwin(const ColArgs 
 // work spread over the chip at 4096 positions, ~0.1 ms at the 32768 positions of a configs[3] shard
 // (the radix sort it replaces took 30-60 us in several launches at 4096).
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ unsigned long long sort_key(const float* __restrict__ scan, const Geom& ge, const int p) {
+// pc = positions per chunk: the order is chunk-major over equal ranges of positions (one chunk: pc = total), so that
+// the sorted ranks [c pc, (c + 1) pc) are exactly the positions of chunk c (chunked multi-mode line search).  Chunk
+// and angle are both monotone in p, so (chunk, angle) orders like chunk * ptheta + angle.
+__device__ __forceinline__ unsigned long long sort_key(const float* __restrict__ scan, const Geom& ge, const int p, const int pc) {
     const Pos q = decode_pos(scan, p, ge);
-    if (!q.valid) return ~0ull;
-    const unsigned long long t = (unsigned long long)(p / ge.nscan);
+    const unsigned long long u = (unsigned long long)(p / pc) * (unsigned long long)ge.ptheta + (unsigned long long)(p / ge.nscan);
+    if (!q.valid) return (u << 44) | 0xfffffffffffull;   // skipped positions: last of their (chunk, angle) group
     unsigned long long bx = (unsigned long long)(q.sx / kBucketPx), sy = (unsigned long long)q.sy;
-    if (bx > 0x3fffffull) bx = 0x3fffffull;
+    if (bx > 0x3ffffeull) bx = 0x3ffffeull;
     if (sy > 0x3fffffull) sy = 0x3fffffull;
-    return (t << 44) | (bx << 22) | sy;
+    return (u << 44) | (bx << 22) | sy;
 }
 
 __global__ __launch_bounds__(256) void k_rank_positions(const float* __restrict__ scan, const Geom ge, const int total,
                                                         const int nslices, int* __restrict__ counts,
-                                                        int* __restrict__ tickets, int* __restrict__ order) {
+                                                        int* __restrict__ tickets, int* __restrict__ order, const int pc) {
     __shared__ unsigned long long keys[256];
     __shared__ int last;
     const int tid = threadIdx.x;
     const int iblock = blockIdx.x / nslices, slice = blockIdx.x % nslices;
     const int i = iblock * 256 + tid;
-    const unsigned long long ki = i < total ? sort_key(scan, ge, i) : ~0ull;
+    const unsigned long long ki = i < total ? sort_key(scan, ge, i, pc) : ~0ull;
     const int ntiles = (total + 255) / 256;
     int cnt = 0;
     for (int tile = slice; tile < ntiles; tile += nslices) {
         const int jl = tile * 256 + tid;
         __syncthreads();
-        keys[tid] = jl < total ? sort_key(scan, ge, jl) : ~0ull;
+        keys[tid] = jl < total ? sort_key(scan, ge, jl, pc) : ~0ull;
         __syncthreads();
         const int j0 = tile * 256;
 #pragma unroll 8

@@ -31,6 +31,14 @@ struct ColArgs {
     int k_begin, k_end; // range of k handled by this launch; ADJ_* read scratch tile k - k_begin
     int ngroups;        // position groups; grid = nstrips * ngroups
     int strip0, nstrips;
+    // forward pass of several probe modes per launch (k_cols_gatherwin<..., NM > 1>): probes and farplanes
+    const c32* auxm[4];
+    c32* dstm[4];
+    // deterministic adjoints (option "deterministic"): the per-workgroup sums are added to a 64-bit fixed-point
+    // image with INTEGER atomics (associative, so the result does not depend on the arrival order) instead of
+    // float atomics on dst; *det_scale is the power of two that converts a float to that fixed point
+    long long* det_acc;
+    const float* det_scale;
 };
 
 struct RowArgs {

@@ -86,6 +86,12 @@ struct ptycho_handle_s {
     double* reg_shifts = nullptr;         // sub-pixel shifts [positions][2]
     int use_window = 1;       // 0: direct-atomics object adjoint (k_cols<ADJ_OBJ>)
     int use_split = 1;        // ndet = 256: one radix-16 step of the DFT over y runs in the row pass
+    int deterministic = 0;    // 1: adjoints accumulate in 64-bit fixed point (integer atomics): bitwise reproducible results
+    long long* det_acc = nullptr;   // fixed-point image, 2 words per object (or probe) element, kept zero between calls
+    float* det_scale = nullptr;     // device: power of two float -> fixed point
+    double* det_words = nullptr;    // device: max |g|, max |probe or object| as float bits (k_cg_absmax)
+    int compact_modes = 0;    // multi-mode CG: 0 = slot pairs (2k, 2k+1); M = compact layout A(k) = k, one shared B = M
+    int sort_chunks = 1;      // position order is chunk-major over this many equal position ranges (chunked line search)
     int use_fused = 0;        // ndet = 256 forward as one launch (k_fwd_fused256): 0 off (default: measured slower), 1 / 2 class tiles per pass
     c32* prbp = nullptr;      // fused forward: c * probe in a zero-bordered ndet x ndet frame, per angle
     int trust_order = 0;      // 1: caller vouches that scan is unchanged since the last sort
@@ -326,6 +332,43 @@ int do_fwd(ptycho_handle h, c32* g, const c32* f, const float* scan, const c32* 
 }
 
 
+// ---- deterministic adjoints (option "deterministic"): set-up before / fold-in after the column pass ----
+int det_begin(ptycho_handle h, ColArgs& ca, const c32* gsrc, long long gcount, const c32* other, long long ocount, int flg, hipStream_t st) {
+    const Geom& ge = h->ge;
+    const size_t nobj = (size_t)ge.ptheta * ge.nz * ge.n, nprb = (size_t)ge.ptheta * ge.nprb * ge.nprb;
+    if (!h->det_acc) {
+        const size_t words = 2 * (nobj > nprb ? nobj : nprb);
+        HIP_TRY(hipMalloc((void**)&h->det_acc, words * sizeof(long long)));
+        HIP_TRY(hipMemset(h->det_acc, 0, words * sizeof(long long)));
+        HIP_TRY(hipMalloc((void**)&h->det_scale, sizeof(float)));
+        HIP_TRY(hipMalloc((void**)&h->det_words, 2 * sizeof(double)));
+    }
+    HIP_TRY(hipMemsetAsync(h->det_words, 0, 2 * sizeof(double), st));
+    long long gg = (gcount + 255) / 256;
+    if (gg > (long long)h->n_cu * 16) gg = (long long)h->n_cu * 16;
+    hipLaunchKernelGGL(k_cg_absmax, dim3((unsigned)gg), dim3(256), 0, st, gsrc, gcount, h->det_words);
+    long long go = (ocount + 255) / 256;
+    if (go > (long long)h->n_cu * 4) go = (long long)h->n_cu * 4;
+    hipLaunchKernelGGL(k_cg_absmax, dim3((unsigned)go), dim3(256), 0, st, other, ocount, h->det_words + 1);
+    // additions per element: every position of an angle may touch it, four bilinear taps (object) / once (probe)
+    const long long nadd = flg == 0 ? 4ll * ge.nscan : (long long)ge.nscan;
+    hipLaunchKernelGGL(k_det_scale, dim3(1), dim3(1), 0, st, (const double*)h->det_words, (const double*)(h->det_words + 1), ge.ndet, nadd,
+                       h->det_scale);
+    HIP_TRY(hipGetLastError());
+    ca.det_acc = h->det_acc;
+    ca.det_scale = h->det_scale;
+    return PTYCHO_OK;
+}
+int det_end(ptycho_handle h, c32* dst, int flg, hipStream_t st) {
+    const Geom& ge = h->ge;
+    const long long n = flg == 0 ? (long long)ge.ptheta * ge.nz * ge.n : (long long)ge.ptheta * ge.nprb * ge.nprb;
+    long long g = (n + 255) / 256;
+    if (g > (long long)h->n_cu * 4) g = (long long)h->n_cu * 4;
+    hipLaunchKernelGGL(k_det_finish, dim3((unsigned)g), dim3(256), 0, st, dst, h->det_acc, n, (const float*)h->det_scale);
+    HIP_TRY(hipGetLastError());
+    return PTYCHO_OK;
+}
+
 template <int N>
 int do_adj(ptycho_handle h, c32* f, const c32* g, const float* scan, c32* prb, int flg, hipStream_t st) {
     constexpr int C = ColCfg<N>::C;
@@ -338,6 +381,12 @@ int do_adj(ptycho_handle h, c32* f, const c32* g, const float* scan, c32* prb, i
     // object are neighbours in time, which is what the LDS overlap-add window needs
     int rc = sort_positions(h, scan, st);
     if (rc) return rc;
+    ColArgs det{};
+    if (h->deterministic) {
+        if (!(h->use_window && WinCfg<N>::fits)) return fail(PTYCHO_ERR_ARG, "option deterministic needs the windowed adjoint kernels (ndet <= 512)");
+        rc = det_begin(h, det, g, total * N * N, flg == 0 ? prb : f, flg == 0 ? (long long)ge.ptheta * ge.nprb * ge.nprb : (long long)ge.ptheta * ge.nz * ge.n, flg, st);
+        if (rc) return rc;
+    }
     for (long long k0 = 0; k0 < total; k0 += h->chunk) {
         const long long k1 = k0 + h->chunk < total ? k0 + h->chunk : total;
         RowArgs ra{};
@@ -353,6 +402,7 @@ int do_adj(ptycho_handle h, c32* f, const c32* g, const float* scan, c32* prb, i
         ColArgs ca{};
         ca.src = h->scratch; ca.scan = scan; ca.table = h->table; ca.ge = ge;
         ca.order = h->order; ca.k_begin = (int)k0; ca.k_end = (int)k1; ca.strip0 = strip0; ca.nstrips = nstrips;
+        ca.det_acc = det.det_acc; ca.det_scale = det.det_scale;
         if constexpr (N == 256) {
             if (split) {
                 if (flg == 0) {
@@ -383,6 +433,7 @@ int do_adj(ptycho_handle h, c32* f, const c32* g, const float* scan, c32* prb, i
         }
         if (rc) return rc;
     }
+    if (h->deterministic) return det_end(h, flg == 0 ? f : prb, flg, st);
     return PTYCHO_OK;
 }
 
@@ -409,11 +460,14 @@ int do_fft2(ptycho_handle h, c32* dst, const c32* src, long long nbatch, int dir
 
 
 // ---- CG-stage helpers ----------------------------------------------------------------
+inline int slot_a(ptycho_handle h, int k) { return h->compact_modes ? k : 2 * k; }
+inline int slot_b(ptycho_handle h, int k) { return h->compact_modes ? h->compact_modes : 2 * k + 1; }
 inline bool slot_ready(ptycho_handle h, int slot) { return slot >= 0 && slot < ptycho_handle_s::kSlots && h->work[slot]; }
 int ensure_work(ptycho_handle h, int slot) {
     if (slot < 0 || slot >= ptycho_handle_s::kSlots) return fail(PTYCHO_ERR_ARG, "work slot out of range");
     if (!h->work[slot]) {
-        const size_t total = (size_t)h->ge.ptheta * h->ge.nscan;
+        // kMaxModes spare tiles: the M chunk parts of the shared slot of the compact layout take M ceil(total / M) tiles
+        const size_t total = (size_t)h->ge.ptheta * h->ge.nscan + kMaxModes;
         HIP_TRY(hipMalloc((void**)&h->work[slot], total * h->ge.ndet * h->ge.ndet * sizeof(c32)));
         HIP_TRY(hipMemset(h->work[slot], 0, total * h->ge.ndet * h->ge.ndet * sizeof(c32)));
     }
@@ -457,6 +511,12 @@ int do_cg_adj_cols(ptycho_handle h, int slot, c32* f, const float* scan, c32* pr
     ca.src = h->work[slot]; ca.scan = scan; ca.table = h->table; ca.ge = ge; ca.natural_tiles = 1;
     ca.order = h->order; ca.k_begin = 0; ca.k_end = (int)total; ca.strip0 = strip0; ca.nstrips = nstrips;
     const bool window = h->use_window && WinCfg<N>::fits;
+    if (h->deterministic) {
+        if (!window) return fail(PTYCHO_ERR_ARG, "option deterministic needs the windowed adjoint kernels (ndet <= 512)");
+        rc = det_begin(h, ca, h->work[slot], total * N * N, flg == 0 ? prb : f,
+                       flg == 0 ? (long long)ge.ptheta * ge.nprb * ge.nprb : (long long)ge.ptheta * ge.nz * ge.n, flg, st);
+        if (rc) return rc;
+    }
     if (flg == 0) {
         ca.dst = f; ca.aux = prb;
         if (window) {
@@ -472,6 +532,7 @@ int do_cg_adj_cols(ptycho_handle h, int slot, c32* f, const float* scan, c32* pr
             rc = launch_cols<N, +1, M_ADJ_PRB>(h, ca, st);
         }
     }
+    if (!rc && h->deterministic) rc = det_end(h, flg == 0 ? f : prb, flg, st);
     return rc;
 }
 
@@ -482,7 +543,7 @@ int do_cg_rows(ptycho_handle h, RowFusedArgs a, hipStream_t st) {
     int strip0, nstrips;
     strip_range<N>(h->ge, strip0, nstrips);
     a.table = h->table;
-    a.nrows = (long long)h->ge.ptheta * h->ge.nscan * N;
+    if (a.nrows <= 0) a.nrows = (long long)h->ge.ptheta * h->ge.nscan * N;   // preset: a range of positions (chunked line search)
     a.xa = strip0 * C; a.xb = (strip0 + nstrips) * C;
     long long nb = (a.nrows + B - 1) / B;
     long long grid = nb < (long long)h->n_cu * 8 ? nb : (long long)h->n_cu * 8;
@@ -598,8 +659,9 @@ int sort_positions(ptycho_handle h, const float* scan, hipStream_t st) {
     if (nslices < 1) nslices = 1;
     {
         ProfSpan ps(h, K_SORT, st);
+        const int pc = (total + h->sort_chunks - 1) / h->sort_chunks;   // positions per chunk
         hipLaunchKernelGGL(k_rank_positions, dim3((unsigned)(iblocks * nslices)), dim3(256), 0, st, scan, h->ge, total, nslices,
-                           h->sort_counts, h->sort_counts + total, h->order);
+                           h->sort_counts, h->sort_counts + total, h->order, pc);
     }
     HIP_TRY(hipGetLastError());
     return PTYCHO_OK;
@@ -615,8 +677,8 @@ int alloc_sort(ptycho_handle h) {
 }
 
 void release(ptycho_handle h) {
-    void* ptrs[] = {h->bs_chirp, h->bs_hfilt, h->table, h->scratch, h->order, h->sort_counts, h->zoom_phase, h->prbp, h->reg_ip, h->reg_best, h->reg_shifts};
-    h->zoom_phase = nullptr; h->prbp = nullptr; h->bs_chirp = nullptr; h->bs_hfilt = nullptr; h->reg_ip = nullptr; h->reg_best = nullptr; h->reg_shifts = nullptr;
+    void* ptrs[] = {h->det_acc, h->det_scale, h->det_words, h->bs_chirp, h->bs_hfilt, h->table, h->scratch, h->order, h->sort_counts, h->zoom_phase, h->prbp, h->reg_ip, h->reg_best, h->reg_shifts};
+    h->det_acc = nullptr; h->det_scale = nullptr; h->det_words = nullptr; h->zoom_phase = nullptr; h->prbp = nullptr; h->bs_chirp = nullptr; h->bs_hfilt = nullptr; h->reg_ip = nullptr; h->reg_best = nullptr; h->reg_shifts = nullptr;
     for (auto& w : h->work) { if (w) (void)hipFree(w); w = nullptr; }
     for (void* q : ptrs)
         if (q) (void)hipFree(q);
@@ -770,6 +832,18 @@ int ptycho_set_option(ptycho_handle h, const char* name, long long value) {
         h->use_split = value != 0;
         return PTYCHO_OK;
     }
+    if (std::strcmp(name, "deterministic") == 0) {
+        h->deterministic = value != 0;
+        return PTYCHO_OK;
+    }
+    if (std::strcmp(name, "compact_modes") == 0) {   // value = number of probe modes (0: slot pairs); also makes the order chunk-major
+        if (value < 0 || value > kMaxModes || (value > 0 && (long long)h->ge.ptheta * value > (1 << 19)))
+            return fail(PTYCHO_ERR_ARG, "compact_modes must be in [0, 8]");
+        h->compact_modes = (int)value;
+        h->sort_chunks = value > 1 ? (int)value : 1;
+        h->order_scan = nullptr;
+        return PTYCHO_OK;
+    }
     if (std::strcmp(name, "fused") == 0) {
         h->use_fused = (int)value;
         return PTYCHO_OK;
@@ -905,8 +979,8 @@ int ptycho_cg_intensity_modes(ptycho_handle h, int nmodes, void* inten, const vo
     if (sums && !data) return fail(PTYCHO_ERR_ARG, "null operand");
     RowFusedArgs a{};
     for (int k = 0; k < nmodes; ++k) {
-        if (!slot_ready(h, 2 * k)) return fail(PTYCHO_ERR_ARG, "work slot is empty");
-        a.sm[k] = h->work[2 * k];
+        if (!slot_ready(h, slot_a(h, k))) return fail(PTYCHO_ERR_ARG, "work slot is empty");
+        a.sm[k] = h->work[slot_a(h, k)];
     }
     a.nmodes = nmodes;
     a.acc1 = (float*)inten; a.data = (const float*)data; a.sums = sums;
@@ -921,10 +995,12 @@ int ptycho_cg_linesearch_modes(ptycho_handle h, int mode0, int nmodes, const voi
     if (!data || !costs) return fail(PTYCHO_ERR_ARG, "null operand");
     if (mode0 < 0 || nmodes < 1 || mode0 + nmodes > kMaxModes) return fail(PTYCHO_ERR_ARG, "modes must lie in [0, 8)");
     if (ncand < 1 || ncand > kMaxCand) return fail(PTYCHO_ERR_ARG, "ncand must be in [1, 16]");
+    if (h->compact_modes && nmodes != 1) return fail(PTYCHO_ERR_ARG, "compact slot layout: one mode pair per call (use ptycho_cg_linesearch_chunk)");
     RowFusedArgs a{};
-    for (int k = 0; k < 2 * nmodes; ++k) {
-        if (!slot_ready(h, 2 * mode0 + k)) return fail(PTYCHO_ERR_ARG, "work slot is empty");
-        a.sm[k] = h->work[2 * mode0 + k];
+    for (int k = 0; k < nmodes; ++k) {
+        if (!slot_ready(h, slot_a(h, mode0 + k)) || !slot_ready(h, slot_b(h, mode0 + k))) return fail(PTYCHO_ERR_ARG, "work slot is empty");
+        a.sm[2 * k] = h->work[slot_a(h, mode0 + k)];
+        a.sm[2 * k + 1] = h->work[slot_b(h, mode0 + k)];
     }
     a.nmodes = nmodes;
     a.data = (const float*)data; a.inten = (const float*)inten; a.sums = costs; a.ab = ab;
@@ -1138,13 +1214,14 @@ int ptycho_cg_obj_dir(ptycho_handle h, double* state, int first, const void* sca
 int ptycho_cg_ls_next(ptycho_handle h, double* state, int which, int pass, const void* data, int use_ab, void* stream) {
     int rc = check_stage(h, state);
     if (rc) return rc;
-    if (which < 0 || which > 1 || pass < 1 || pass > 3 || !data) return fail(PTYCHO_ERR_ARG, "bad line-search stage");
+    if (which < 0 || which > 1 || pass < 1 || pass > 4 || !data) return fail(PTYCHO_ERR_ARG, "bad line-search stage");
     hipStream_t st = (hipStream_t)stream;
-    const int next_groups = pass == 1 ? 1 : (pass == 2 ? kLsGroupsMax : 0);
+    // passes: <= 16 step lengths (sized from the last accepted index), then 16, 32, 64 more: 2^-106 < 1e-32 is covered
+    const int next_groups = pass == 1 ? 1 : (pass == 2 ? 2 : (pass == 3 ? 4 : 0));
     hipLaunchKernelGGL(k_cg_ls_decide, dim3(1), dim3(1), 0, st, state, which,
                        which == 0 ? (int)PTYCHO_ST_GAMMA_PSI : (int)PTYCHO_ST_GAMMA_PRB, next_groups);
     HIP_TRY(hipGetLastError());
-    if (pass == 3) return PTYCHO_OK;
+    if (pass == 4) return PTYCHO_OK;
     return ls_pass(h, data, use_ab, state, st);
 }
 
@@ -1235,3 +1312,138 @@ int ptycho_cg_prb_finish(ptycho_handle h, double* state, void* prb, const void* 
 }
 
 }  // extern "C"
+
+
+// ---- several probe modes per column pass; compact slot layout with a chunked line search ----
+namespace {
+
+template <int N, int NM>
+int launch_gatherwin_modes(ptycho_handle h, ColArgs a, hipStream_t st) {
+    using CC = ColCfg<N>;
+    const int np = a.k_end - a.k_begin;
+    if (np <= 0 || a.nstrips <= 0) return PTYCHO_OK;
+    int nseg = (h->n_cu * 4 + a.nstrips - 1) / a.nstrips;
+    if (nseg < 1) nseg = 1;
+    int seglen = (np + nseg - 1) / nseg;
+    if (seglen < 8) seglen = 8;
+    if (seglen > kRunMax) seglen = kRunMax;
+    nseg = (np + seglen - 1) / seglen;
+    a.nt = 0;
+    {
+        ProfSpan ps(h, K_COLS_FWD, st);
+        hipLaunchKernelGGL((k_cols_gatherwin<N, M_FWD, false, NM>), dim3((unsigned)(a.nstrips * nseg)), dim3(CC::NT), 0, st, a, seglen);
+    }
+    HIP_TRY(hipGetLastError());
+    return PTYCHO_OK;
+}
+
+template <int N>
+int do_cg_fwd_cols_modes(ptycho_handle h, int nmodes, c32* const* dst, const c32* f, const float* scan, const c32* const* prbs,
+                         int k_begin, int k_end, hipStream_t st) {
+    const Geom& ge = h->ge;
+    int strip0, nstrips;
+    strip_range<N>(ge, strip0, nstrips);
+    int rc = sort_positions(h, scan, st);
+    if (rc) return rc;
+    ColArgs ca{};
+    ca.src = f; ca.scan = scan; ca.table = h->table; ca.ge = ge; ca.order = h->order;
+    ca.k_begin = k_begin; ca.k_end = k_end; ca.strip0 = strip0; ca.nstrips = nstrips;
+    int k = 0;
+    while (k < nmodes) {
+        const int left = nmodes - k;
+        if constexpr (WinCfg<N>::fits && N <= 512) {
+            if (left >= 4) {
+                for (int j = 0; j < 4; ++j) { ca.auxm[j] = prbs[k + j]; ca.dstm[j] = dst[k + j]; }
+                rc = launch_gatherwin_modes<N, 4>(h, ca, st);
+                if (rc) return rc;
+                k += 4;
+                continue;
+            }
+            if (left >= 2) {
+                for (int j = 0; j < 2; ++j) { ca.auxm[j] = prbs[k + j]; ca.dstm[j] = dst[k + j]; }
+                rc = launch_gatherwin_modes<N, 2>(h, ca, st);
+                if (rc) return rc;
+                k += 2;
+                continue;
+            }
+        }
+        ca.aux = prbs[k]; ca.dst = dst[k];
+        if constexpr (WinCfg<N>::fits) {
+            rc = launch_gatherwin<N, M_FWD>(h, ca, st);
+        } else {
+            ColArgs cb = ca;
+            cb.order = nullptr;
+            if (k_begin != 0 || k_end != ge.ptheta * ge.nscan) return fail(PTYCHO_ERR_ARG, "position ranges need the windowed column pass (ndet <= 512)");
+            rc = launch_cols<N, -1, M_FWD>(h, cb, st);
+        }
+        if (rc) return rc;
+        ++k;
+    }
+    return PTYCHO_OK;
+}
+
+template <int N>
+int do_ls_chunk(ptycho_handle h, RowFusedArgs a, hipStream_t st) { return do_cg_rows<N, EP_LINESEARCH_M>(h, a, st); }
+
+}  // namespace
+
+extern "C" int ptycho_cg_fwd_cols_modes(ptycho_handle h, int nmodes, int mode0, const void* f, const void* scan,
+                                        const void* const* prbs, int into_b, int chunk, void* stream) {
+    int rc = check_handle(h);
+    if (rc) return rc;
+    if (!f || !scan || !prbs || nmodes < 1 || mode0 < 0 || mode0 + nmodes > kMaxModes) return fail(PTYCHO_ERR_ARG, "bad operand");
+    const long long total = (long long)h->ge.ptheta * h->ge.nscan;
+    const size_t tile = (size_t)h->ge.ndet * h->ge.ndet;
+    c32* dst[kMaxModes];
+    const c32* pr[kMaxModes];
+    int k_begin = 0, k_end = (int)total;
+    if (into_b) {   // B sub-slots: mode k of the positions of this chunk at tile k * pc of the shared slot
+        if (!h->compact_modes || nmodes != h->compact_modes || mode0 != 0 || chunk < 0 || chunk >= h->sort_chunks)
+            return fail(PTYCHO_ERR_ARG, "chunked column pass needs the compact slot layout and all modes");
+        const long long pc = (total + h->sort_chunks - 1) / h->sort_chunks;
+        k_begin = (int)(chunk * pc);
+        k_end = (int)((chunk + 1) * pc < total ? (chunk + 1) * pc : total);
+        rc = ensure_work(h, slot_b(h, 0));
+        if (rc) return rc;
+        for (int k = 0; k < nmodes; ++k) dst[k] = h->work[slot_b(h, 0)] + (size_t)k * pc * tile - (size_t)k_begin * tile;
+    } else {
+        for (int k = 0; k < nmodes; ++k) {
+            rc = ensure_work(h, slot_a(h, mode0 + k));
+            if (rc) return rc;
+            dst[k] = h->work[slot_a(h, mode0 + k)];
+        }
+    }
+    for (int k = 0; k < nmodes; ++k) {
+        if (!prbs[k]) return fail(PTYCHO_ERR_ARG, "null probe");
+        pr[k] = (const c32*)prbs[k];
+    }
+    hipStream_t st = (hipStream_t)stream;
+    PTY_DISPATCH(h->ge.ndet, (do_cg_fwd_cols_modes<NN>(h, nmodes, dst, (const c32*)f, (const float*)scan, pr, k_begin, k_end, st)));
+}
+
+extern "C" int ptycho_cg_linesearch_chunk(ptycho_handle h, int chunk, const void* data, const double* ab, double gamma0,
+                                          int ncand, double* costs, void* stream) {
+    int rc = check_handle(h);
+    if (rc) return rc;
+    if (!data || !costs) return fail(PTYCHO_ERR_ARG, "null operand");
+    if (!h->compact_modes || chunk < 0 || chunk >= h->sort_chunks) return fail(PTYCHO_ERR_ARG, "chunked line search needs the compact slot layout");
+    if (ncand < 1 || ncand > kMaxCand) return fail(PTYCHO_ERR_ARG, "ncand must be in [1, 16]");
+    const int M = h->compact_modes;
+    const long long total = (long long)h->ge.ptheta * h->ge.nscan;
+    const long long pc = (total + h->sort_chunks - 1) / h->sort_chunks;
+    const long long p0 = chunk * pc, p1 = (chunk + 1) * pc < total ? (chunk + 1) * pc : total;
+    if (p1 <= p0) return PTYCHO_OK;
+    const size_t tile = (size_t)h->ge.ndet * h->ge.ndet;
+    RowFusedArgs a{};
+    for (int k = 0; k < M; ++k) {
+        if (!slot_ready(h, slot_a(h, k)) || !slot_ready(h, slot_b(h, 0))) return fail(PTYCHO_ERR_ARG, "work slot is empty");
+        a.sm[2 * k] = h->work[slot_a(h, k)] + (size_t)p0 * tile;
+        a.sm[2 * k + 1] = h->work[slot_b(h, 0)] + (size_t)k * pc * tile;
+    }
+    a.nmodes = M;
+    a.data = (const float*)data + (size_t)p0 * tile; a.sums = costs; a.ab = ab;
+    a.gamma0 = (float)gamma0; a.ncand = ncand;
+    a.nrows = (p1 - p0) * h->ge.ndet;
+    hipStream_t st = (hipStream_t)stream;
+    PTY_DISPATCH(h->ge.ndet, (do_ls_chunk<NN>(h, a, st)));
+}

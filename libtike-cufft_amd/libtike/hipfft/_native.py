@@ -20,6 +20,7 @@ SYMBOLS = ("ptycho_create", "ptycho_free", "ptycho_destroy", "ptycho_get",
            "ptycho_cg_project_multi",
            "ptycho_cg_intensity_modes", "ptycho_cg_linesearch_modes",
            "ptycho_cg_cross", "ptycho_cg_argmax", "ptycho_cg_zoom",
+           "ptycho_cg_fwd_cols_modes", "ptycho_cg_linesearch_chunk",
            "ptycho_cg_obj_begin", "ptycho_cg_obj_grad", "ptycho_cg_obj_dir", "ptycho_cg_ls_next",
            "ptycho_cg_obj_finish", "ptycho_cg_prb_grad", "ptycho_cg_prb_dir", "ptycho_cg_prb_finish",
            "ptycho_last_error", "ptycho_version")
@@ -62,6 +63,8 @@ cg_cross = _sig("ptycho_cg_cross", _i, _vp, _i, _i, ctypes.c_double, _vp, _vp)
 cg_argmax = _sig("ptycho_cg_argmax", _i, _vp, _i, _vp, _vp)
 cg_zoom = _sig("ptycho_cg_zoom", _i, _vp, _vp, _vp, _vp, _vp, _i, _i, ctypes.c_double, _vp, _vp)
 _d = ctypes.c_double
+cg_fwd_cols_modes = _sig("ptycho_cg_fwd_cols_modes", _i, _vp, _i, _i, _vp, _vp, ctypes.POINTER(_vp), _i, _i, _vp)
+cg_linesearch_chunk = _sig("ptycho_cg_linesearch_chunk", _i, _vp, _i, _vp, _vp, _d, _i, _vp, _vp)
 cg_obj_begin = _sig("ptycho_cg_obj_begin", _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp)
 cg_obj_grad = _sig("ptycho_cg_obj_grad", _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp)
 cg_obj_dir = _sig("ptycho_cg_obj_dir", _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp)
@@ -73,7 +76,7 @@ cg_prb_finish = _sig("ptycho_cg_prb_finish", _i, _vp, _vp, _vp, _vp, _vp)
 #: word offsets of the device-resident CG state (enum PTYCHO_ST_* in include/ptycho_hip.h)
 ST_A, ST_B, ST_COST, ST_COST2 = 0, 1, 2, 3
 ST_GAMMA_PSI, ST_GAMMA_PRB, ST_LS_FAILED, ST_HINT, ST_COSTS, ST_WORDS = 12, 13, 19, 20, 24, 128
-ST_NCOSTS = 6 * 17
+ST_NCOSTS = 4 * 17
 profile = _sig("ptycho_profile", _i, _vp, _i)
 profile_read = _sig("ptycho_profile_read", _i, _vp, ctypes.POINTER(ctypes.c_double),
                     ctypes.POINTER(_ll), _i)

@@ -139,6 +139,11 @@ class PtychoHIP:
         """ndet = 256: split the DFT over y between the column and the row pass (default on)."""
         nat.check(nat.set_option(self._h, b"split", int(bool(on))))
 
+    def set_deterministic(self, on=True):
+        """Adjoints accumulate in 64-bit fixed point (integer atomics): bitwise reproducible results
+        (the reference's float ``atomicAdd``, kernels.cu:73-80,92-93, is not).  ndet <= 512."""
+        nat.check(nat.set_option(self._h, b"deterministic", int(bool(on))))
+
     def set_fused(self, tiles=2):
         """ndet = 256: forward operator as one launch (``k_fwd_fused256``), ``tiles`` = 0 (off), 1 or 2."""
         nat.check(nat.set_option(self._h, b"fused", int(tiles)))
@@ -655,7 +660,7 @@ class CGPtychoSolver(PtychoHIP):
         device and the line search is decided there (C ABI ``ptycho_cg_obj_* / prb_* / ls_next``): an
         iteration is ~13 library calls and no device synchronisation; the host reads the state back only
         when it logs (every ``log_every`` iterations, as the reference prints every 32).  With a process
-        group the three scalar messages of a search and the two gradients are all-reduced in between."""
+        group the scalar messages of a search and the two gradients are all-reduced in between."""
         dev = data.device
         data = self._operand(data, torch.float32, (self.ptheta, self.nscan, self.ndet, self.ndet), "data")
         psi = self._operand(psi, torch.complex64, (self.ptheta, self.nz, self.n), "psi").clone()
@@ -678,7 +683,7 @@ class CGPtychoSolver(PtychoHIP):
         dist_on = self.group is not None
 
         def line_search(which, use_ab):
-            for p in (1, 2, 3):
+            for p in (1, 2, 3, 4):
                 if dist_on:
                     self._allreduce(costs)
                 nat.check(nat.cg_ls_next(h, sp, which, p, _ptr(data), use_ab, S))
@@ -830,19 +835,26 @@ class CGPtychoSolver(PtychoHIP):
             ncand = 16
 
     def _run_fused_multi(self, data, psi, scan, probe, piter, recover_prb):
-        """``CGPtychoSolver.run`` (ptycho.py:283-488), gaussian model, 2..8 incoherent probe
-        modes.  Every mode k owns a pair of work slots: 2k holds the column pass of
-        fwd(psi, probe_k) -- made once per step and shared by the intensity sum, the
-        projection and the line search (the probe rescale a/b is linear and applied on the
-        fly, as in the single-mode loop) -- and 2k+1 the projected residual, then the column
-        pass of fwd(dpsi, probe_k).  The summed intensity is a float32 array; the line-search
-        terms p1, p2, p3 are summed over the modes in registers (C ABI ``ptycho_cg_*``)."""
+        """``CGPtychoSolver.run`` (ptycho.py:283-488), gaussian model, 2..8 incoherent probe modes.
+
+        Work slots (one farplane each), compact layout: slot k holds the column pass of
+        fwd(psi, probe_k) -- made once per step for all modes by ONE launch that gathers the object
+        patch once per position (C ABI ``ptycho_cg_fwd_cols_modes``; the reference gathers per mode,
+        ptycho.py:330-333) and shared by the intensity sum, the projection and the line search (the
+        probe rescale a/b is linear and applied on the fly) -- and ONE further slot M is shared by all
+        modes: projected residual of one mode at a time, direction column passes.  The summed intensity
+        is a float32 array written once (no per-mode farplane is ever materialised); the object line
+        search, which needs fwd(dpsi, probe_k) of every mode at once, runs over M position ranges with
+        the M direction column passes of a range side by side in the shared slot
+        (``ptycho_cg_linesearch_chunk``): M + 1 farplanes instead of 2 M, same work."""
         dev = data.device
         M = probe.shape[1]
         data = self._operand(data, torch.float32, (self.ptheta, self.nscan, self.ndet, self.ndet), "data")
         psi = self._operand(psi, torch.complex64, (self.ptheta, self.nz, self.n), "psi")
         self._operand(scan, torch.float32, (self.ptheta, self.nscan, 2), "scan")
         assert probe.dtype == torch.complex64
+        nat.check(nat.set_option(self._h, b"compact_modes", M))
+        self._scan_key = None                   # the position order becomes chunk-major: sort again
         nscan_total = self._nscan_total()
         sums = torch.zeros(2, dtype=torch.float64, device=dev)
         cost = torch.zeros(1, dtype=torch.float64, device=dev)
@@ -850,12 +862,45 @@ class CGPtychoSolver(PtychoHIP):
         costs = torch.zeros(33, dtype=torch.float64, device=dev)
         inten = torch.empty_like(data)
         mode = lambda arr, k: arr[:, k].contiguous()
-        A = lambda k: 2 * k          # column pass of fwd(psi, probe_k)
-        B = lambda k: 2 * k + 1      # residual of mode k, then column pass of fwd(direction, .)
+        A = lambda k: k              # column pass of fwd(psi, probe_k)
+        B = M                        # shared: residual of one mode, then column passes of fwd(direction, .)
+        vpp = ctypes.c_void_p * M
+
+        def fwd_cols_all(obj, modes, into_b=0, chunk=0):     # one launch per <= 4 modes, shared patch gather
+            self._note_scan(scan)
+            keep = [mode(modes, k) for k in range(M)]
+            ptrs = vpp(*[t.data_ptr() for t in keep])
+            nat.check(nat.cg_fwd_cols_modes(self._h, M, 0, _ptr(obj), _ptr(scan), ptrs, into_b, chunk, _stream()))
 
         def sum_intensity(stats=None):          # inten = sum_k |slot A(k)|^2 (+ a, b of :342-343) in one pass
             nat.check(nat.cg_intensity_modes(self._h, M, _ptr(inten), _ptr(data),
                                              _ptr(stats) if stats is not None else None, _stream()))
+
+        def object_line_search(ab):
+            """``_modes_line_search`` for all modes, chunk by chunk; t1_k = (a/b) * slot A(k) (old probe),
+            t2_k = column pass of fwd(dpsi, probe_k) (rescaled probe) in part k of the shared slot."""
+            hints = self.__dict__.setdefault("_ls_hint", {})
+            ncand = min(16, (max(2, hints.get("psi", 14) + 2) + 3) & ~3)
+            gamma0, tried = 1.0, 0
+            while True:
+                costs.zero_()
+                for c in range(M):
+                    fwd_cols_all(dpsi, probe, into_b=1, chunk=c)
+                    nat.check(nat.cg_linesearch_chunk(self._h, c, _ptr(data), _ptr(ab), gamma0, ncand,
+                                                      _ptr(costs), _stream()))
+                self._allreduce(costs)
+                cc = costs.to(torch.float32).cpu().numpy()
+                step = gamma0
+                for j in range(ncand):
+                    if not (cc[j] > cc[ncand]):
+                        hints["psi"] = tried + j
+                        return step
+                    if step < 1e-32:
+                        warnings.warn("Line search failed for conjugate gradient.")
+                        hints["psi"] = 14
+                        return 0
+                    step *= 0.5
+                gamma0, tried, ncand = step, tried + ncand, 16
 
         dpsi = gradpsi0 = None
         dprb = gradprb0 = gradprb = None
@@ -863,75 +908,77 @@ class CGPtychoSolver(PtychoHIP):
         if self.verbose:
             print("# congujate gradient parameters\n"
                   "iteration, step size object, step size probe, function min")
-        for i in range(piter):
-            # 1) object step ------------------------------------------------------------
-            for k in range(M):                                                  # :329-333
-                self._cg_fwd_cols(A(k), psi, scan, mode(probe, k))
-            sums.zero_()
-            sum_intensity(sums)
-            self._allreduce(sums)
-            ab32 = sums.to(torch.float32)
-            probe *= (ab32[0] / ab32[1])                                        # :344
-            gradpsi = torch.zeros((self.ptheta, self.nz, self.n), dtype=torch.complex64, device=dev)
-            cost.zero_()
-            for k in range(M):                                                  # :349-356
-                pk = mode(probe, k)
-                # slot A(k) was made with the probe before its rescale: fpsi = (g s)(1/s)
-                nat.check(nat.cg_project_multi(self._h, A(k), B(k), _ptr(data), _ptr(inten), _ptr(sums), 1,
-                                               _ptr(cost if k == 0 else scratch_cost), _stream()))
-                g = torch.zeros_like(gradpsi)
-                nat.check(nat.cg_adj_cols(self._h, B(k), _ptr(g), _ptr(scan), _ptr(pk), 0, _stream()))
-                gradpsi += g / (torch.max(torch.abs(pk)) ** 2)
-            self._allreduce(gradpsi)
-            dpsi = _dy_direction(i, gradpsi, gradpsi0, dpsi)
-            gradpsi0 = gradpsi
-            for k in range(M):                                                  # :383-391
-                self._cg_fwd_cols(B(k), dpsi, scan, mode(probe, k))
-            # t1_k = (a/b) * slot A(k) (old probe), t2_k = slot B(k) (rescaled probe)
-            gammapsi = 0.5 * self._modes_line_search(0, M, data, None, sums, costs, "psi")
+        try:
+            for i in range(piter):
+                # 1) object step ------------------------------------------------------------
+                fwd_cols_all(psi, probe)                                            # :329-333
+                sums.zero_()
+                sum_intensity(sums)
+                self._allreduce(sums)
+                ab32 = sums.to(torch.float32)
+                probe *= (ab32[0] / ab32[1])                                        # :344
+                gradpsi = torch.zeros((self.ptheta, self.nz, self.n), dtype=torch.complex64, device=dev)
+                cost.zero_()
+                for k in range(M):                                                  # :349-356
+                    pk = mode(probe, k)
+                    # slot A(k) was made with the probe before its rescale: fpsi = (g s)(1/s)
+                    nat.check(nat.cg_project_multi(self._h, A(k), B, _ptr(data), _ptr(inten), _ptr(sums), 1,
+                                                   _ptr(cost if k == 0 else scratch_cost), _stream()))
+                    g = torch.zeros_like(gradpsi)
+                    nat.check(nat.cg_adj_cols(self._h, B, _ptr(g), _ptr(scan), _ptr(pk), 0, _stream()))
+                    gradpsi += g / (torch.max(torch.abs(pk)) ** 2)
+                self._allreduce(gradpsi)
+                dpsi = _dy_direction(i, gradpsi, gradpsi0, dpsi)
+                gradpsi0 = gradpsi
+                gammapsi = 0.5 * object_line_search(sums)                           # :383-393
 
-            if i > 0:                                                           # :398-403
-                scan[0, :] += self._position_shifts(psi, dpsi, gammapsi, scan, probe).to(scan.dtype)
-            psi = psi + gammapsi * dpsi
+                if i > 0:                                                           # :398-403
+                    scan[0, :] += self._position_shifts(psi, dpsi, gammapsi, scan, probe).to(scan.dtype)
+                psi = psi + gammapsi * dpsi
 
-            # 2) probe step, one mode at a time ------------------------------------------
-            if recover_prb:                                                     # :409-465
-                if i == 0:
-                    gradprb = probe * 0
-                    gradprb0 = probe * 0
-                    dprb = probe * 0
-                for m in range(M):
-                    # slots A(k) = fwd(psi, probe_k) for the current psi and probes: all of them
-                    # after the object step, then only the mode that was just updated
-                    for k in (range(M) if m == 0 else (m - 1,)):
-                        self._cg_fwd_cols(A(k), psi, scan, mode(probe, k))
-                    sum_intensity()                                             # absfprb (= p1 below)
-                    scratch_cost.zero_()
-                    nat.check(nat.cg_project_multi(self._h, A(m), B(m), _ptr(data), _ptr(inten), None, 0,
-                                                   _ptr(scratch_cost), _stream()))
-                    g = torch.zeros((self.ptheta, self.nprb, self.nprb), dtype=torch.complex64, device=dev)
-                    nat.check(nat.cg_adj_cols(self._h, B(m), _ptr(psi), _ptr(scan), _ptr(g), 1, _stream()))
-                    self._allreduce(g)
-                    gradprb[:, m] = g / torch.max(torch.abs(psi)) ** 2 / nscan_total * M
+                # 2) probe step, one mode at a time ------------------------------------------
+                if recover_prb:                                                     # :409-465
                     if i == 0:
-                        dprb[:, m] = -gradprb[:, m]
-                    else:
-                        dprb[:, m] = -gradprb[:, m] + (
-                            torch.linalg.norm(gradprb[:, m]) ** 2
-                            / (torch.sum(torch.conj(dprb[:, m]) * (gradprb[:, m] - gradprb0[:, m])))
-                            * dprb[:, m])
-                    gradprb0[:, m] = gradprb[:, m]
-                    self._cg_fwd_cols(B(m), psi, scan, mode(dprb, m))
-                    # p1 = summed intensity, p2 = |fwd(psi, dprb_m)|^2, p3 = 2 Re(fwd(psi, probe_m) conj(.))
-                    gammaprb = 0.5 * self._modes_line_search(m, 1, data, inten, None, costs, "prb%d" % m)
-                    probe[:, m] = probe[:, m] + gammaprb * dprb[:, m]
+                        gradprb = probe * 0
+                        gradprb0 = probe * 0
+                        dprb = probe * 0
+                    for m in range(M):
+                        # slots A(k) = fwd(psi, probe_k) for the current psi and probes: all of them
+                        # after the object step, then only the mode that was just updated
+                        if m == 0:
+                            fwd_cols_all(psi, probe)
+                        else:
+                            self._cg_fwd_cols(A(m - 1), psi, scan, mode(probe, m - 1))
+                        sum_intensity()                                             # absfprb (= p1 below)
+                        scratch_cost.zero_()
+                        nat.check(nat.cg_project_multi(self._h, A(m), B, _ptr(data), _ptr(inten), None, 0,
+                                                       _ptr(scratch_cost), _stream()))
+                        g = torch.zeros((self.ptheta, self.nprb, self.nprb), dtype=torch.complex64, device=dev)
+                        nat.check(nat.cg_adj_cols(self._h, B, _ptr(psi), _ptr(scan), _ptr(g), 1, _stream()))
+                        self._allreduce(g)
+                        gradprb[:, m] = g / torch.max(torch.abs(psi)) ** 2 / nscan_total * M
+                        if i == 0:
+                            dprb[:, m] = -gradprb[:, m]
+                        else:
+                            dprb[:, m] = -gradprb[:, m] + (
+                                torch.linalg.norm(gradprb[:, m]) ** 2
+                                / (torch.sum(torch.conj(dprb[:, m]) * (gradprb[:, m] - gradprb0[:, m])))
+                                * dprb[:, m])
+                        gradprb0[:, m] = gradprb[:, m]
+                        self._cg_fwd_cols(B, psi, scan, mode(dprb, m))
+                        # p1 = summed intensity, p2 = |fwd(psi, dprb_m)|^2, p3 = 2 Re(fwd(psi, probe_m) conj(.))
+                        gammaprb = 0.5 * self._modes_line_search(m, 1, data, inten, None, costs, "prb%d" % m)
+                        probe[:, m] = probe[:, m] + gammaprb * dprb[:, m]
 
-            if i % self.log_every == 0:
-                c = cost.clone()
-                self._allreduce(c)
-                self.history.append((i, float(gammapsi), float(gammaprb), float(c.to(torch.float32))))
-                if self.verbose:
-                    print("%4d, %.3e, %.3e, %.7e" % self.history[-1])
+                if i % self.log_every == 0:
+                    c = cost.clone()
+                    self._allreduce(c)
+                    self.history.append((i, float(gammapsi), float(gammaprb), float(c.to(torch.float32))))
+                    if self.verbose:
+                        print("%4d, %.3e, %.3e, %.7e" % self.history[-1])
+        finally:
+            nat.check(nat.set_option(self._h, b"compact_modes", 0))
+            self._scan_key = None
         return {"psi": psi, "probe": probe}
 
     def run(self, data, psi, scan, probe, piter, model="gaussian",

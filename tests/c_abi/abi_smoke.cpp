@@ -20,7 +20,7 @@ typedef std::complex<float> cf;
 int main() {
     const size_t ptheta = 1, nz = 160, n = 176, nscan = 49, ndet = 64, nprb = 48;
     ptycho_handle h = nullptr;
-    if (ptycho_create(&h, ptheta, nz, n, nscan, 48, nprb) == 0) { std::printf("FAIL: ndet=48 accepted\n"); return 1; }
+    if (ptycho_create(&h, ptheta, 1300, 1300, nscan, 1100, nprb) == 0) { std::printf("FAIL: ndet=1100 accepted\n"); return 1; }   // neither <= 1024 nor a power of two
     CK(ptycho_create(&h, ptheta, nz, n, nscan, ndet, nprb));
     if (ptycho_get(h, 4) != (long long)ndet || ptycho_get(h, 5) != (long long)nprb) { std::printf("FAIL get\n"); return 1; }
 

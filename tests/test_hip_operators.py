@@ -356,3 +356,24 @@ def test_operators_any_detector_size_match_oracle(pt, ndet, nprb, ntheta):
     r1 = np.vdot(a.astype(np.complex128), p["psi"].astype(np.complex128))
     r2 = np.vdot(b.astype(np.complex128), prb.astype(np.complex128))
     assert abs(lhs - r1) < 1e-5 * abs(lhs) and abs(lhs - r2) < 1e-5 * abs(lhs)
+
+
+@pytest.mark.parametrize("ndet,nprb", [(256, 256), (128, 96), (512, 512)])
+def test_deterministic_adjoints_are_bitwise_reproducible(pt, ndet, nprb):
+    """Option "deterministic": the object / probe adjoints accumulate in 64-bit fixed point with integer
+    atomics, so repeated calls give identical bits (the reference's float atomicAdd, kernels.cu:73-80,92-93,
+    and the default path here do not), and the result agrees with the default path to float32 rounding."""
+    p = syn.make_problem(12, 12, 9, nprb, ndet, seed=4)
+    rng = np.random.default_rng(2)
+    y = (rng.standard_normal((1, 144, ndet, ndet)) + 1j * rng.standard_normal((1, 144, ndet, ndet))).astype(np.complex64)
+    with pt.PtychoCuFFT(144, nprb, ndet, 1, p["nz"], p["n"]) as slv:
+        psi, scan, prb, yd = dev(p["psi"]), dev(p["scan"]), dev(p["probe"]), dev(y)
+        ref_a, ref_b = host(slv.adj(yd, scan, prb)), host(slv.adj_probe(yd, scan, psi))
+        slv.set_deterministic(True)
+        runs = [(host(slv.adj(yd, scan, prb)), host(slv.adj_probe(yd, scan, psi))) for _ in range(3)]
+        slv.set_deterministic(False)
+    for a, b in runs[1:]:
+        np.testing.assert_array_equal(a, runs[0][0])
+        np.testing.assert_array_equal(b, runs[0][1])
+    assert np.abs(runs[0][0] - ref_a).max() <= 2e-6 * np.abs(ref_a).max()
+    assert np.abs(runs[0][1] - ref_b).max() <= 2e-6 * np.abs(ref_b).max()
