@@ -71,8 +71,9 @@ def cfg3_figures(pt, syn, dev, iters):
     slv = pt.CGPtychoSolver(R * R, ndet, ndet, 1, nz, n)
     slv.verbose = False
     prb0 = modes[:, 0].contiguous()
-    g = slv.fwd(psi, scan, prb0)
-    slv.adj(g, scan, prb0)
+    for _ in range(3):      # warm-up: both farplane blocks of the alternating pattern below exist afterwards
+        g = slv.fwd(psi, scan, prb0)
+        slv.adj(g, scan, prb0)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(5):

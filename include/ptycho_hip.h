@@ -140,6 +140,7 @@ int ptycho_cg_linesearch_chunk(ptycho_handle h, int chunk, const void* data, con
  *                     [ptheta][nscan][ndet][ndet], kept for the zoomed DFT); slot2 <- IDFT_x(product)
  *   ptycho_cg_argmax  IDFT_y of the slot, |.|, first maximum per position as
  *                     best[p] = (float bits of the value << 32) | (0xffffffff - flat index) */
+/* image_product = NULL (here and in ptycho_cg_zoom): the product is kept in work slot 2 instead of a caller buffer */
 int ptycho_cg_cross(ptycho_handle h, int slot1, int slot2, double gamma, void* image_product,
                     void* stream);
 int ptycho_cg_argmax(ptycho_handle h, int slot, void* best, void* stream);

@@ -130,6 +130,24 @@ struct Fft {
         }
     }
 
+    // twiddles of ONE step (kernels that cannot afford all NSTEP - 1 sets in registers at once re-read a set
+    // from an LDS copy of the table right before the step that uses it)
+    template <int ST>
+    PTY_FN void init_step(int j0, const c32* __restrict__ table) {
+        static_assert(ST >= 1 && ST < P::NSTEP, "steps 1 .. NSTEP-1 have twiddles");
+        constexpr int R = P::radix(ST), Ns = P::ns(ST);
+#pragma unroll
+        for (int b = 0; b < E / R; ++b) {
+            const int j = j0 + b * T;
+#pragma unroll
+            for (int t = 0; t < R; ++t) {
+                const int k = ((j % Ns) * t * (N / (Ns * R))) & (N - 1);
+                const c32 w = table[k];
+                tw[(ST - 1) * E + b * R + t] = DIR < 0 ? w : cconj(w);
+            }
+        }
+    }
+
     // v[b*R + t] = src(j + t*N/R)
     template <int ST, class Src>
     PTY_FN void load(c32* v, int j0, Src src) const {

@@ -189,6 +189,27 @@ int launch_adjwin(ptycho_handle h, ColArgs a, hipStream_t st, int wg_target = 0)
     return PTYCHO_OK;
 }
 
+template <int N>
+int launch_adjwin2(ptycho_handle h, ColArgs a, hipStream_t st) {
+    const int np = a.k_end - a.k_begin;
+    if (np <= 0 || a.nstrips <= 0) return PTYCHO_OK;
+    static const int wg_mult = std::getenv("PTYCHO_HIP_ADJWGS") ? std::atoi(std::getenv("PTYCHO_HIP_ADJWGS")) : 6;   // three per CU resident
+    int nseg = (h->n_cu * wg_mult + a.nstrips - 1) / a.nstrips;
+    if (nseg < 1) nseg = 1;
+    int seglen = (np + nseg - 1) / nseg;
+    if (seglen < 8) seglen = 8;
+    if (seglen > kRunMax) seglen = kRunMax;
+    nseg = (np + seglen - 1) / seglen;
+    static const int nt_mode_a = std::getenv("PTYCHO_HIP_NT") ? std::atoi(std::getenv("PTYCHO_HIP_NT")) : 0;
+    a.nt = nt_mode_a;
+    {
+        ProfSpan ps(h, K_COLS_ADJ_OBJ, st);
+        hipLaunchKernelGGL((k_cols_adjwin2<N>), dim3((unsigned)(a.nstrips * nseg)), dim3(256), 0, st, a, seglen);
+    }
+    HIP_TRY(hipGetLastError());
+    return PTYCHO_OK;
+}
+
 template <int N, int MODE, bool SPLIT = false>
 int launch_gatherwin(ptycho_handle h, ColArgs a, hipStream_t st, int wg_target = 0) {
     using CC = ColCfg<N>;
@@ -407,7 +428,8 @@ int do_adj(ptycho_handle h, c32* f, const c32* g, const float* scan, c32* prb, i
             if (split) {
                 if (flg == 0) {
                     ca.dst = f; ca.aux = prb;
-                    rc = launch_adjwin<N, true>(h, ca, st);
+                    static const bool old_adjwin = std::getenv("PTYCHO_HIP_ADJWIN1") != nullptr;   // comparison knob
+                    rc = old_adjwin ? launch_adjwin<N, true>(h, ca, st) : launch_adjwin2<N>(h, ca, st);
                 } else {
                     ca.dst = prb; ca.aux = f;
                     rc = launch_gatherwin<N, M_ADJ_PRB, true>(h, ca, st);
@@ -685,6 +707,7 @@ void release(ptycho_handle h) {
     h->table = nullptr; h->scratch = nullptr; h->order = nullptr; h->sort_counts = nullptr;
     for (auto& sp : h->spans) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
     h->spans.clear();
+
 }
 
 }  // namespace
@@ -767,9 +790,9 @@ int ptycho_create(ptycho_handle* out, size_t ptheta, size_t nz, size_t n, size_t
     if (env) h->use_split = std::atoi(env) != 0;
     env = std::getenv("PTYCHO_HIP_FUSED");
     if (env) h->use_fused = std::atoi(env);
+
     h->chunk = default_chunk(h->ge);
-    int rc = alloc_scratch(h);
-    if (!rc) rc = alloc_sort(h);
+    int rc = alloc_sort(h);   // the adjoint's scratch (up to 4 GiB) is allocated by the first ptycho_adj call
     if (rc) {
         release(h);
         delete h;
@@ -817,7 +840,8 @@ int ptycho_set_option(ptycho_handle h, const char* name, long long value) {
     if (std::strcmp(name, "chunk") == 0) {
         h->chunk = value > 0 ? value : default_chunk(h->ge);
         HIP_TRY(hipDeviceSynchronize());
-        return alloc_scratch(h);
+        if (h->scratch) { HIP_TRY(hipFree(h->scratch)); h->scratch = nullptr; }
+        return PTYCHO_OK;
     }
     if (std::strcmp(name, "window") == 0) {
         h->use_window = value != 0;
@@ -890,6 +914,10 @@ int ptycho_adj(ptycho_handle h, void* f, const void* g, const void* scan, void* 
     if (rc) return rc;
     if (!g || !f || !scan || !prb) return fail(PTYCHO_ERR_ARG, "null operand");
     if (flg != 0 && flg != 1) return fail(PTYCHO_ERR_ARG, "flg must be 0 (object) or 1 (probe)");
+    if (!h->scratch) {
+        rc = alloc_scratch(h);
+        if (rc) return rc;
+    }
     hipStream_t st = (hipStream_t)stream;
     if (h->bs_m) { PTY_DISPATCH(h->bs_m, (do_adj_generic<NN>(h, (c32*)f, (const c32*)g, (const float*)scan, (c32*)prb, flg, st))); }
     PTY_DISPATCH(h->ge.ndet, (do_adj<NN>(h, (c32*)f, (const c32*)g, (const float*)scan, (c32*)prb, flg, st)));
@@ -1047,9 +1075,11 @@ int do_cg_argmax(ptycho_handle h, int slot, unsigned long long* best, hipStream_
 extern "C" int ptycho_cg_cross(ptycho_handle h, int slot1, int slot2, double gamma, void* image_product, void* stream) {
     int rc = check_handle(h);
     if (rc) return rc;
-    if (!image_product) return fail(PTYCHO_ERR_ARG, "null operand");
-    if (h->ge.nprb != h->ge.ndet) {
-        // with a padded probe the zero columns of the slots are not materialised; the row pass masks them
+    if (!image_product) {   // NULL: the image product lives in work slot 2 (free during the position correction)
+        rc = ensure_work(h, 2);
+        if (rc) return rc;
+        if (slot1 == 2 || slot2 == 2) return fail(PTYCHO_ERR_ARG, "slot 2 is taken by the image product");
+        image_product = h->work[2];
     }
     if (!slot_ready(h, slot1) || !slot_ready(h, slot2))
         return fail(PTYCHO_ERR_ARG, "work slot is empty");
@@ -1073,7 +1103,11 @@ extern "C" int ptycho_cg_zoom(ptycho_handle h, const void* image_product, const 
                               const void* lz, int nc, int ups, double upsample_factor, void* shifts, void* stream) {
     int rc = check_handle(h);
     if (rc) return rc;
-    if (!image_product || !best || !vt || !lz || !shifts) return fail(PTYCHO_ERR_ARG, "null operand");
+    if (!image_product) {   // NULL: work slot 2 (see ptycho_cg_cross)
+        if (!slot_ready(h, 2)) return fail(PTYCHO_ERR_ARG, "work slot is empty");
+        image_product = h->work[2];
+    }
+    if (!best || !vt || !lz || !shifts) return fail(PTYCHO_ERR_ARG, "null operand");
     const int N = h->ge.ndet;
     const int nthreads = N > 256 ? N : 256;
     if (N % 16 != 0 || N > 1024) return fail(PTYCHO_ERR_ARG, "zoomed DFT kernel needs ndet %% 16 == 0 and ndet <= 1024");
@@ -1348,18 +1382,19 @@ int do_cg_fwd_cols_modes(ptycho_handle h, int nmodes, c32* const* dst, const c32
     ColArgs ca{};
     ca.src = f; ca.scan = scan; ca.table = h->table; ca.ge = ge; ca.order = h->order;
     ca.k_begin = k_begin; ca.k_end = k_end; ca.strip0 = strip0; ca.nstrips = nstrips;
+    static const int nm_max = std::getenv("PTYCHO_HIP_NMMAX") ? std::atoi(std::getenv("PTYCHO_HIP_NMMAX")) : 4;   // comparison knob
     int k = 0;
     while (k < nmodes) {
         const int left = nmodes - k;
         if constexpr (WinCfg<N>::fits && N <= 512) {
-            if (left >= 4) {
+            if (left >= 4 && nm_max >= 4) {
                 for (int j = 0; j < 4; ++j) { ca.auxm[j] = prbs[k + j]; ca.dstm[j] = dst[k + j]; }
                 rc = launch_gatherwin_modes<N, 4>(h, ca, st);
                 if (rc) return rc;
                 k += 4;
                 continue;
             }
-            if (left >= 2) {
+            if (left >= 2 && nm_max >= 2) {
                 for (int j = 0; j < 2; ++j) { ca.auxm[j] = prbs[k + j]; ca.dstm[j] = dst[k + j]; }
                 rc = launch_gatherwin_modes<N, 2>(h, ca, st);
                 if (rc) return rc;

@@ -449,6 +449,20 @@ def _argmax2d(a):
 
 
 def _zoom_shifts_native(op, image_product, best, upsample_factor):
+    if image_product is None:          # the product lives in work slot 2 of the handle (ptycho_cg_cross with NULL)
+        dev = best.device
+        fac = _zoom_real_factors(op.ndet, int(np.ceil(upsample_factor * 1.5)), upsample_factor, dev)
+        if fac is None or op.ndet % 16 or op.ndet > 1024:
+            return None
+        vt, lz, nc = fac
+        shifts = torch.empty((best.shape[0], 2), dtype=torch.float64, device=dev)
+        nat.check(nat.cg_zoom(op._h, None, _ptr(best), _ptr(vt), _ptr(lz), nc, int(np.ceil(upsample_factor * 1.5)),
+                              float(upsample_factor), _ptr(shifts), _stream()))
+        return shifts
+    return _zoom_shifts_native_ip(op, image_product, best, upsample_factor)
+
+
+def _zoom_shifts_native_ip(op, image_product, best, upsample_factor):
     """Sub-pixel stage of the registration through the fused HIP kernels
     (``ptycho_cg_zoom``): ``best`` holds the whole-pixel peaks in ``ptycho_cg_argmax``'s packed
     form (int64, low word ``0xffffffff - flat index``); returns the float64 ``[nb, 2]`` shifts
@@ -599,8 +613,12 @@ class CGPtychoSolver(PtychoHIP):
             return register_translation_batch(tmp1, tmp2, upsample_factor=100, space="fourier", op=self)
         self._cg_fwd_cols(0, psi, scan, ones)
         self._cg_fwd_cols(1, dpsi, scan, ones)
-        ip = torch.empty((self.nscan, self.ndet, self.ndet), dtype=torch.complex64, device=psi.device)
-        nat.check(nat.cg_cross(self._h, 0, 1, float(gammapsi), _ptr(ip), _stream()))
+        # three or more probe modes (compact slot layout): the image product goes to work slot 2, which is
+        # free here, instead of a farplane-sized tensor of its own
+        in_slot = probe.shape[1] >= 3 and _zoom_real_factors(self.ndet, 150, 100, psi.device) is not None \
+            and self.ndet % 16 == 0 and self.ndet <= 1024
+        ip = None if in_slot else torch.empty((self.nscan, self.ndet, self.ndet), dtype=torch.complex64, device=psi.device)
+        nat.check(nat.cg_cross(self._h, 0, 1, float(gammapsi), _ptr(ip) if ip is not None else None, _stream()))
         best = torch.empty(self.nscan, dtype=torch.int64, device=psi.device)
         nat.check(nat.cg_argmax(self._h, 1, _ptr(best), _stream()))
         shifts = _zoom_shifts_native(self, ip, best, 100)

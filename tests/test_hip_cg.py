@@ -233,3 +233,43 @@ def test_cg_at_a_cropped_detector_size(pt):
     for (i, gp, gq, c), (io, gpo, gqo, co) in zip(hist, ora.history):
         assert (i, gp, gq) == (io, gpo, gqo) and abs(c - co) <= 1e-4 * abs(co)
     assert np.abs(got["psi"] - want["psi"]).max() < 2e-4 * np.abs(want["psi"]).max()
+
+
+def test_fused_registration_right_on_its_first_launch():
+    """DESIGN.md (round 1) recorded an occupancy-capped variant of the registration row pass that was wrong on its
+    first launch in a process and right afterwards.  That variant is gone; this pins the shipped path: in a FRESH
+    process, the very first solver calls are the fused position-correction kernels (two ones-probe column passes,
+    CROSS, arg-max, zoom) on never-used work slots, checked against the un-fused registration (HIP operators +
+    register_translation_batch through torch)."""
+    import subprocess
+    import sys
+    import os
+    code = r'''
+import sys, os
+root = %r
+sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "libtike-cufft_amd"))
+import numpy as np, torch
+import libtike.hipfft as pt
+from libtike.hipfft import synthetic as syn
+from libtike.hipfft.ptycho import register_translation_batch
+for ndet in (256, 64):
+    p = syn.make_problem(5, 6, 9, ndet, ndet, seed=3)
+    rng = np.random.default_rng(1)
+    dev = lambda x: torch.as_tensor(np.ascontiguousarray(x), device="cuda")
+    psi, scan = dev(p["psi"]), dev(p["scan"])
+    dpsi = dev((rng.standard_normal(p["psi"].shape) + 1j * rng.standard_normal(p["psi"].shape)).astype(np.complex64) * 0.05)
+    probe = dev(p["probe"][:, None])
+    slv = pt.CGPtychoSolver(p["nscan"], ndet, ndet, 1, p["nz"], p["n"])
+    got = slv._position_shifts(psi, dpsi, 0.25, scan, probe).cpu().numpy()     # first launches of this handle
+    ones = torch.ones_like(probe[:, 0])
+    t1 = slv.fwd(psi, scan, ones)[0]
+    t2 = slv.fwd(psi + 0.25 * dpsi, scan, ones)[0]
+    want = register_translation_batch(t1, t2, 100, "fourier").cpu().numpy()
+    again = slv._position_shifts(psi, dpsi, 0.25, scan, probe).cpu().numpy()
+    assert np.array_equal(got, again), (ndet, np.abs(got - again).max())
+    assert np.abs(got - want).max() <= 0.0100001, (ndet, np.abs(got - want).max())   # one step of the 1/100 px grid at most
+    assert (np.abs(got - want) > 1e-9).mean() < 0.1, ndet
+print("ok")
+''' % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))),)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stdout + out.stderr
