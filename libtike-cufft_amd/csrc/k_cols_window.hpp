@@ -234,213 +234,6 @@ __global__ __launch_bounds__(ColCfg<N>::NT) void k_cols_adjwin(const ColArgs a, 
 }
 
 // ---------------------------------------------------------------------------
-// Object adjoint for the split layout (N = 256), second generation: no T tile.  k_cols_adjwin<N, true> writes
-// T = conj(c prb) near to LDS (37 KiB) so that other threads can read the bilinear neighbours; with the 42 KiB
-// window that leaves two workgroups per CU, and the kernel is bound by latency (VALU busy 17 %).  Here the
-// neighbour along x comes from the adjacent lane (DPP row shift: thread (j0, c) and (j0, c - 1) sit in one
-// 16-lane row), and the neighbour along y is never fetched: every thread adds its own h[y] (1 - fy) to window
-// row sy + y, then -- after one barrier -- h[y] fy to row sy + y + 1.  The 17th output column (T[., 15] fx) goes
-// through a 2 KiB column buffer and costs one read-modify-write per thread.  LDS 46 KiB -> three workgroups
-// per CU; LDS instructions per position and thread 84 (was 88), barriers 2 (as before).
-// ---------------------------------------------------------------------------
-__device__ __forceinline__ c32 dpp_row_shr1(c32 v) {   // value of the lane one to the left in the 16-lane row, 0 for lane 0
-    const int x = __builtin_amdgcn_update_dpp(0, __float_as_int(v.x), 0x111, 0xf, 0xf, true);
-    const int y = __builtin_amdgcn_update_dpp(0, __float_as_int(v.y), 0x111, 0xf, 0xf, true);
-    return c32{__int_as_float(x), __int_as_float(y)};
-}
-
-template <int N>
-__global__ __launch_bounds__(256, 3) void k_cols_adjwin2(const ColArgs a, const int seglen) {
-    static_assert(N == 256, "written for the 16 x 16 split plan");
-    using P = Plan<N>;
-    using F = Fft<P, +1>;
-    constexpr int E = P::E, T = P::T, C = 16, NT = 256;
-    constexpr int LAST = P::NSTEP - 1;
-    constexpr int WC = WinCfg<N>::WC, H = WinCfg<N>::H;
-    static_assert(ColCfg<N>::C == C && ColCfg<N>::NT == NT, "strip geometry");
-    __shared__ c32 win[H * WC];
-    __shared__ c32 ecol[2][N + 2];   // ecol[k & 1][1 + y] = T[y][15] fx of position k (double buffered); [.][0] = 0
-
-    const int tid = threadIdx.x;
-    const int c = tid % C, j0 = tid / C;
-    const int strip = blockIdx.x % a.nstrips, seg = blockIdx.x / a.nstrips;
-    const int x0 = (a.strip0 + strip) * C;
-    const int x = x0 + c;
-    const Geom ge = a.ge;
-    const int ix = x - ge.pad;
-    const bool col_ok = ix >= 0 && ix < ge.nprb;
-    const float cinv = 1.0f / (float)N;
-    const c32 zero = c32{0.0f, 0.0f};
-
-    // the 15 twiddles of the step are re-read from an LDS copy of the table for every position instead of living
-    // in 32 VGPRs across the whole loop: with them the kernel does not fit the 168 registers of three waves per SIMD
-    __shared__ c32 wtab[N];
-    wtab[tid] = a.table[tid];
-    F fft;
-    for (int o = tid; o < H * WC; o += NT) win[o] = zero;
-    for (int o = tid; o < 2 * (N + 2); o += NT) (&ecol[0][0])[o] = zero;
-
-    c32 pr[E];   // c * probe strip, natural order (row j0 + m*T); zero on padding
-    int cur_t = -1;
-    int t_w = -1, X0 = 0, Ybase = 0, Ytop = 0;   // live object rows [Ybase, Ytop), columns [X0, X0+WC)
-
-    auto flush = [&](int ya, int yb) {   // add rows [ya, yb) to the object and clear them
-        if (yb <= ya) return;
-        const int cnt = (yb - ya) * WC;
-        for (int o = tid; o < cnt; o += NT) {
-            const int Y = ya + o / WC, col = o % WC;
-            const int slot = (Y % H) * WC + col;
-            const c32 v = win[slot];
-            win[slot] = zero;
-            const int X = X0 + col;
-            if ((v.x != 0.0f || v.y != 0.0f) && Y < ge.nz && X >= 0 && X < ge.n) {
-                const size_t e = ((size_t)t_w * ge.nz + Y) * ge.n + X;
-                if (a.det_acc) {
-                    const float sc = *a.det_scale;
-                    atomicAdd(reinterpret_cast<unsigned long long*>(a.det_acc + 2 * e), (unsigned long long)__float2ll_rn(v.x * sc));
-                    atomicAdd(reinterpret_cast<unsigned long long*>(a.det_acc + 2 * e + 1), (unsigned long long)__float2ll_rn(v.y * sc));
-                } else {
-                    float* op = reinterpret_cast<float*>(a.dst + e);
-                    atomicAdd(op, v.x);
-                    atomicAdd(op + 1, v.y);
-                }
-            }
-        }
-    };
-
-    const int kb = a.k_begin + seg * seglen;
-    const int ke = kb + seglen < a.k_end ? kb + seglen : a.k_end;
-    __shared__ RunMeta rm;
-    load_run(rm, a.order, a.scan, kb, ke, tid);
-    struct St { int p, t; Pos q; bool have; };
-    auto decode = [&](int k) -> St {
-        St st;
-        st.have = k < ke;
-        st.p = 0; st.t = 0; st.q = Pos{0, 0, 0.f, 0.f, false, false};
-        if (!st.have) return st;
-        st.p = uni_i(rm.p[k - kb]);
-        st.t = st.p / ge.nscan;
-        st.q = decode_xy(uni_f(rm.py[k - kb]), uni_f(rm.px[k - kb]), ge);
-        return st;
-    };
-    auto tile_of = [&](const St& st, int k) {
-        return a.src + (size_t)(a.natural_tiles ? st.p : (k - a.k_begin)) * N * N;
-    };
-    auto load_tile = [&](c32* v, const St& st, int k) {
-        const c32* tile_in = tile_of(st, k);
-        if (a.nt & 8)
-            fft.template load<1>(v, j0, [&](int i) { return __builtin_nontemporal_load(tile_in + (size_t)i * N + x); });
-        else
-            fft.template load<1>(v, j0, [&](int i) { return tile_in[(size_t)i * N + x]; });
-    };
-
-    __syncthreads();
-    St st = decode(kb);
-    c32 v[E];
-    if (st.have && st.q.valid) load_tile(v, st, kb);
-    int par = 0;   // column buffer of the position being processed (skipped positions do not toggle it)
-    for (int k = kb; k < ke; ++k) {
-        St nx = decode(k + 1);
-        if (!st.q.valid) {   // skipped position: nothing to add; fetch the next tile
-            if (nx.have && nx.q.valid) load_tile(v, nx, k + 1);
-            st = nx;
-            continue;
-        }
-        const Pos q = st.q;
-        if (st.t != cur_t) {
-            const c32* prb = a.aux + (size_t)st.t * ge.nprb * ge.nprb;
-#pragma unroll
-            for (int m = 0; m < E; ++m) {
-                const int iy = j0 + m * T - ge.pad;
-                const bool ok = col_ok && iy >= 0 && iy < ge.nprb;
-                const c32 w = prb[ok ? ((size_t)iy * ge.nprb + ix) : 0];
-                pr[m] = ok ? w * cinv : zero;
-            }
-            cur_t = st.t;
-        }
-        // ---- second radix-16 step of the inverse DFT over y (k_rows_split did the first) ----------------
-        {
-            int jz = j0;
-            asm volatile("" : "+v"(jz));   // opaque: keeps the table reads inside the loop
-#pragma unroll
-            for (int t = 1; t < 16; ++t) fft.tw[t] = cconj(wtab[(jz * t) & (N - 1)]);
-            fft.tw[0] = c32{1.0f, 0.0f};
-        }
-        fft.template compute<LAST>(v);
-        c32 h[E];
-        F::to_natural(v, h);
-        if (nx.have && nx.q.valid) load_tile(v, nx, k + 1);   // prefetch under the combine
-        // ---- T = conj(c prb) near, then the bilinear combine along x in registers ------------------------
-        const float wx0 = 1.0f - q.fx, wy0 = 1.0f - q.fy;
-        c32* ec = ecol[par];
-        par ^= 1;
-#pragma unroll
-        for (int m = 0; m < E; ++m) {
-            const c32 w = pr[m];
-            const c32 t = c32{w.x * h[m].x + w.y * h[m].y, w.x * h[m].y - w.y * h[m].x};
-            const c32 left = dpp_row_shr1(t);
-            h[m] = t * wx0 + left * q.fx;     // output column cc = c: T[y][c] (1 - fx) + T[y][c - 1] fx
-            if (c == C - 1) ec[1 + j0 + m * T] = t * q.fx;   // output column cc = 16 (the other buffer is still being read)
-        }
-        __syncthreads();   // A: the previous position's second phase (and its column buffer) is done
-        // ---- window bookkeeping (all quantities are workgroup-uniform) -------------------------------------
-        const int Xa = q.sx + x0 - ge.pad;   // object column of strip column cc = 0
-        const bool fitsw = (st.t == t_w) && Xa >= X0 && Xa + C < X0 + WC && q.sy >= Ybase;
-        if (!fitsw) {
-            flush(Ybase, Ytop);
-            t_w = st.t;
-            X0 = (q.sx / kBucketPx) * kBucketPx + x0 - ge.pad;
-            Ybase = q.sy;
-            Ytop = q.sy;
-            __syncthreads();   // the window is clean before anyone adds at the new anchor
-        } else if (q.sy > Ybase) {
-            flush(Ybase, q.sy < Ytop ? q.sy : Ytop);   // rows below q.sy: not touched by this position
-            Ybase = q.sy;
-            if (Ytop < Ybase) Ytop = Ybase;
-        }
-        if (Ytop < q.sy + ge.nprb + 1) Ytop = q.sy + ge.nprb + 1;
-        const int colw = Xa - X0 + c;
-        int slot = (q.sy + j0 - ge.pad + 2 * H) % H;
-        // ---- phase 1: rows sy + y get h[y] (1 - fy) -----------------------------------------------------------
-        {
-            int s1 = slot;
-#pragma unroll
-            for (int m = 0; m < E; ++m) {
-                const int iy = j0 + m * T - ge.pad;   // rows outside the probe carry T = 0 and may be rows that are being flushed
-                if (iy >= 0 && iy < ge.nprb) win[s1 * WC + colw] += h[m] * wy0;
-                s1 += T;
-                s1 = s1 >= H ? s1 - H : s1;
-                if ((m & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // four read-modify-writes in flight, not sixteen
-            }
-        }
-        __syncthreads();   // B
-        // ---- phase 2: rows sy + y + 1 get h[y] fy; column 16 from the column buffer -------------------------
-        {
-            int s1 = slot + 1 == H ? 0 : slot + 1;
-#pragma unroll
-            for (int m = 0; m < E; ++m) {
-                const int iy = j0 + m * T - ge.pad;
-                if (iy >= 0 && iy < ge.nprb) win[s1 * WC + colw] += h[m] * q.fy;
-                s1 += T;
-                s1 = s1 >= H ? s1 - H : s1;
-                if ((m & 3) == 3) __builtin_amdgcn_sched_barrier(0);
-            }
-            // thread tid owns tile row y = tid of output column 16 (object column Xa + 16)
-            const int col16 = Xa - X0 + C;
-            const int sr = (q.sy + tid - ge.pad + 2 * H) % H;
-            if (tid - ge.pad >= 0 && tid - ge.pad <= ge.nprb) win[sr * WC + col16] += ec[1 + tid] * wy0 + ec[tid] * q.fy;
-            if (tid == 0 && ge.pad == 0) {
-                const int sl = (q.sy + N - ge.pad + 2 * H) % H;
-                win[sl * WC + col16] += ec[N] * q.fy;
-            }
-        }
-        st = nx;
-    }
-    __syncthreads();
-    flush(Ybase, Ytop);
-}
-
-// ---------------------------------------------------------------------------
 // Forward operator / probe adjoint with the object strip cached in LDS.
 // Same run structure as k_cols_adjwin: a workgroup owns C probe columns and a
 // contiguous run of SORTED positions; the object rows it needs slide by a few

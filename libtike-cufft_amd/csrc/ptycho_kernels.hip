@@ -189,27 +189,6 @@ int launch_adjwin(ptycho_handle h, ColArgs a, hipStream_t st, int wg_target = 0)
     return PTYCHO_OK;
 }
 
-template <int N>
-int launch_adjwin2(ptycho_handle h, ColArgs a, hipStream_t st) {
-    const int np = a.k_end - a.k_begin;
-    if (np <= 0 || a.nstrips <= 0) return PTYCHO_OK;
-    static const int wg_mult = std::getenv("PTYCHO_HIP_ADJWGS") ? std::atoi(std::getenv("PTYCHO_HIP_ADJWGS")) : 6;   // three per CU resident
-    int nseg = (h->n_cu * wg_mult + a.nstrips - 1) / a.nstrips;
-    if (nseg < 1) nseg = 1;
-    int seglen = (np + nseg - 1) / nseg;
-    if (seglen < 8) seglen = 8;
-    if (seglen > kRunMax) seglen = kRunMax;
-    nseg = (np + seglen - 1) / seglen;
-    static const int nt_mode_a = std::getenv("PTYCHO_HIP_NT") ? std::atoi(std::getenv("PTYCHO_HIP_NT")) : 0;
-    a.nt = nt_mode_a;
-    {
-        ProfSpan ps(h, K_COLS_ADJ_OBJ, st);
-        hipLaunchKernelGGL((k_cols_adjwin2<N>), dim3((unsigned)(a.nstrips * nseg)), dim3(256), 0, st, a, seglen);
-    }
-    HIP_TRY(hipGetLastError());
-    return PTYCHO_OK;
-}
-
 template <int N, int MODE, bool SPLIT = false>
 int launch_gatherwin(ptycho_handle h, ColArgs a, hipStream_t st, int wg_target = 0) {
     using CC = ColCfg<N>;
@@ -428,8 +407,7 @@ int do_adj(ptycho_handle h, c32* f, const c32* g, const float* scan, c32* prb, i
             if (split) {
                 if (flg == 0) {
                     ca.dst = f; ca.aux = prb;
-                    static const bool old_adjwin = std::getenv("PTYCHO_HIP_ADJWIN1") != nullptr;   // comparison knob
-                    rc = old_adjwin ? launch_adjwin<N, true>(h, ca, st) : launch_adjwin2<N>(h, ca, st);
+                    rc = launch_adjwin<N, true>(h, ca, st);
                 } else {
                     ca.dst = prb; ca.aux = f;
                     rc = launch_gatherwin<N, M_ADJ_PRB, true>(h, ca, st);

@@ -5,7 +5,7 @@ coalesced reads by 2x (MI355X_MICROARCH.md, HBM section) -- both raw and correct
 import csv, glob, sys, collections, re
 
 def short(name):
-    m = re.search(r"(k_[a-z_]+)<([^>]*)>", name)
+    m = re.search(r"(k_[a-z_0-9]+)<([^>]*)>", name)
     if m: return "%s<%s>" % (m.group(1), m.group(2))
     if "radix_sort" in name or "merge_sort" in name: return "rocprim_sort"
     return name[:40]
