@@ -693,7 +693,7 @@ void release(ptycho_handle h) {
 extern "C" {
 
 const char* ptycho_last_error(void) { return g_err.c_str(); }
-const char* ptycho_version(void) { return "ptychohip 0.2 (gfx950)"; }
+const char* ptycho_version(void) { return "ptychohip 0.3 (gfx950)"; }
 
 int ptycho_create(ptycho_handle* out, size_t ptheta, size_t nz, size_t n, size_t nscan, size_t ndet, size_t nprb) {
     if (!out) return fail(PTYCHO_ERR_ARG, "out is null");
