@@ -689,7 +689,7 @@ class CGPtychoSolver(PtychoHIP):
         if st is None or st.device != dev:
             st = self._cg_state = torch.zeros(nat.ST_WORDS, dtype=torch.float64, device=dev)
             st[nat.ST_HINT:nat.ST_HINT + 2] = 14.0
-        h, S = self._h, _stream()
+        h = self._h
         sp, costs = _ptr(st), st[nat.ST_COSTS:nat.ST_COSTS + nat.ST_NCOSTS]
         ones = self.__dict__.get("_ones_probe")
         if ones is None or ones.shape != probe[:, 0].shape or ones.device != dev:
@@ -700,16 +700,15 @@ class CGPtychoSolver(PtychoHIP):
         nscan_total = float(self._nscan_total())
         dist_on = self.group is not None
 
-        def line_search(which, use_ab):
+        def line_search(which, use_ab, S):
             for p in (1, 2, 3, 4):
                 if dist_on:
                     self._allreduce(costs)
                 nat.check(nat.cg_ls_next(h, sp, which, p, _ptr(data), use_ab, S))
 
-        if self.verbose:
-            print("# congujate gradient parameters\n"
-                  "iteration, step size object, step size probe, function min")
-        for i in range(piter):
+        def iteration(first, correct):
+            """One CG iteration as a fixed sequence of launches on the current stream (no host decisions)."""
+            S = _stream()
             # 1) object step (ptycho.py:325-405)
             nat.check(nat.cg_obj_begin(h, sp, _ptr(psi), _ptr(scan), _ptr(probe), _ptr(data), S))
             if dist_on:
@@ -717,20 +716,26 @@ class CGPtychoSolver(PtychoHIP):
             nat.check(nat.cg_obj_grad(h, sp, _ptr(scan), _ptr(probe), _ptr(data), _ptr(grad), S))
             if dist_on:
                 self._allreduce(grad)
-            nat.check(nat.cg_obj_dir(h, sp, int(i == 0), _ptr(scan), _ptr(probe), _ptr(data), _ptr(grad),
+            nat.check(nat.cg_obj_dir(h, sp, first, _ptr(scan), _ptr(probe), _ptr(data), _ptr(grad),
                                      _ptr(grad0), _ptr(dpsi), S))
-            line_search(0, 1)
-            nat.check(nat.cg_obj_finish(h, sp, int(i > 0), _ptr(psi), _ptr(dpsi), _ptr(scan), _ptr(ones),
+            line_search(0, 1, S)
+            nat.check(nat.cg_obj_finish(h, sp, correct, _ptr(psi), _ptr(dpsi), _ptr(scan), _ptr(ones),
                                         _ptr(vt), _ptr(lz), nc, 150, 100.0, S))
             # 2) probe step (ptycho.py:409-465)
             if recover_prb:
                 nat.check(nat.cg_prb_grad(h, sp, _ptr(psi), _ptr(scan), _ptr(probe), _ptr(data), _ptr(gprb), S))
                 if dist_on:
                     self._allreduce(gprb)
-                nat.check(nat.cg_prb_dir(h, sp, int(i == 0), nscan_total, 1.0, _ptr(psi), _ptr(scan), _ptr(data),
+                nat.check(nat.cg_prb_dir(h, sp, first, nscan_total, 1.0, _ptr(psi), _ptr(scan), _ptr(data),
                                          _ptr(gprb), _ptr(gprb0), _ptr(dprb), S))
-                line_search(1, 0)
+                line_search(1, 0, S)
                 nat.check(nat.cg_prb_finish(h, sp, _ptr(probe), _ptr(dprb), S))
+
+        if self.verbose:
+            print("# congujate gradient parameters\n"
+                  "iteration, step size object, step size probe, function min")
+        for i in range(piter):
+            iteration(int(i == 0), int(i > 0))
             if i % self.log_every == 0:
                 snap = st[:nat.ST_LS_FAILED + 1].clone()
                 if dist_on:
