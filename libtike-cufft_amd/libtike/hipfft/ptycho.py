@@ -734,26 +734,28 @@ class CGPtychoSolver(PtychoHIP):
         if self.verbose:
             print("# congujate gradient parameters\n"
                   "iteration, step size object, step size probe, function min")
-        for i in range(piter):
-            iteration(int(i == 0), int(i > 0))
-            if i % self.log_every == 0:
-                snap = st[:nat.ST_LS_FAILED + 1].clone()
-                if dist_on:
-                    self._allreduce(snap[nat.ST_COST:nat.ST_COST + 1])
-                snap = snap.cpu()
-                self.history.append((i, float(snap[nat.ST_GAMMA_PSI]), float(snap[nat.ST_GAMMA_PRB]),
-                                     float(snap[nat.ST_COST].to(torch.float32))))
-                if self.verbose:
-                    print("%4d, %.3e, %.3e, %.7e" % self.history[-1])
+        try:
+            for i in range(piter):
+                iteration(int(i == 0), int(i > 0))
+                if i % self.log_every == 0:
+                    snap = st[:nat.ST_LS_FAILED + 1].clone()
+                    if dist_on:
+                        self._allreduce(snap[nat.ST_COST:nat.ST_COST + 1])
+                    snap = snap.cpu()
+                    self.history.append((i, float(snap[nat.ST_GAMMA_PSI]), float(snap[nat.ST_GAMMA_PRB]),
+                                         float(snap[nat.ST_COST].to(torch.float32))))
+                    if self.verbose:
+                        print("%4d, %.3e, %.3e, %.7e" % self.history[-1])
+        finally:
+            # the native loop moved scan behind torch's back: forget what the operator calls knew about it
+            self._scan_key = None
+            self._scan_trusted = None
+            nat.check(nat.set_option(self._h, b"trust_order", 0))
         failed = int(st[nat.ST_LS_FAILED].item())
         if failed:
             st[nat.ST_LS_FAILED] = 0.0
             for _ in range(failed):
                 warnings.warn("Line search failed for conjugate gradient.")
-        # the native loop moved scan behind torch's back: forget what the operator calls knew about it
-        self._scan_key = None
-        self._scan_trusted = None
-        nat.check(nat.set_option(self._h, b"trust_order", 0))
         return {"psi": psi, "probe": probe}
 
     def _run_fused(self, data, psi, scan, probe, piter, recover_prb):

@@ -35,7 +35,7 @@ def crand(rng, shape):
 
 @st.composite
 def geometry(draw):
-    ndet = draw(st.sampled_from([16, 32, 64, 128]))
+    ndet = draw(st.sampled_from([16, 32, 64, 128, 12, 24, 48, 100]))   # powers of two: fused kernels; others: Bluestein path
     nprb = draw(st.integers(min_value=max(1, ndet // 4), max_value=ndet))
     ntheta = draw(st.integers(1, 2))
     nscan = draw(st.integers(1, 12))
