@@ -147,6 +147,9 @@ int alloc_scratch(ptycho_handle h) {
 
 int sort_positions(ptycho_handle h, const float* scan, hipStream_t st);   // ptycho_sort.hip-style helper below
 
+// shortest run of sorted positions a windowed column workgroup takes (each run pays one window fill)
+static int min_seglen() { static const int v = std::getenv("PTYCHO_HIP_MINSEG") ? std::atoi(std::getenv("PTYCHO_HIP_MINSEG")) : 16; return v < 1 ? 1 : v; }   // 512 positions x 256^2 CG: 8 -> 1.44, 16 -> 1.36, 24 -> 1.51 ms per iteration
+
 template <int N, int DIR, int MODE>
 int launch_cols(ptycho_handle h, ColArgs a, hipStream_t st) {
     using CC = ColCfg<N>;
@@ -176,7 +179,7 @@ int launch_adjwin(ptycho_handle h, ColArgs a, hipStream_t st, int wg_target = 0)
     int nseg = (wg_target + a.nstrips - 1) / a.nstrips;
     if (nseg < 1) nseg = 1;
     int seglen = (np + nseg - 1) / nseg;
-    if (seglen < 8) seglen = 8;
+    if (seglen < min_seglen()) seglen = min_seglen();
     if (seglen > kRunMax) seglen = kRunMax;
     nseg = (np + seglen - 1) / seglen;
     static const int nt_mode_a = std::getenv("PTYCHO_HIP_NT") ? std::atoi(std::getenv("PTYCHO_HIP_NT")) : 0;
@@ -198,7 +201,7 @@ int launch_gatherwin(ptycho_handle h, ColArgs a, hipStream_t st, int wg_target =
     int nseg = (wg_target + a.nstrips - 1) / a.nstrips;
     if (nseg < 1) nseg = 1;
     int seglen = (np + nseg - 1) / nseg;
-    if (seglen < 8) seglen = 8;
+    if (seglen < min_seglen()) seglen = min_seglen();
     if (seglen > kRunMax) seglen = kRunMax;
     nseg = (np + seglen - 1) / seglen;
     if (const char* e = std::getenv("PTYCHO_HIP_COLSEGS")) {   // experiment knob: fewer, longer runs
@@ -1337,7 +1340,7 @@ int launch_gatherwin_modes(ptycho_handle h, ColArgs a, hipStream_t st) {
     int nseg = (h->n_cu * 4 + a.nstrips - 1) / a.nstrips;
     if (nseg < 1) nseg = 1;
     int seglen = (np + nseg - 1) / nseg;
-    if (seglen < 8) seglen = 8;
+    if (seglen < min_seglen()) seglen = min_seglen();
     if (seglen > kRunMax) seglen = kRunMax;
     nseg = (np + seglen - 1) / seglen;
     a.nt = 0;
