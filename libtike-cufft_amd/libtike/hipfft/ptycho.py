@@ -180,25 +180,35 @@ class PtychoHIP:
         self._scan_key = key
 
     # -- operators (ptycho.py:80-123) ---------------------------------------
-    def fwd(self, psi, scan, probe):
-        """Ptychography transform (FQ)."""
+    def fwd(self, psi, scan, probe, out=None):
+        """Ptychography transform (FQ).  ``out``: optional farplane tensor to write into (the reference
+        allocates a fresh one per call, ptycho.py:85-86)."""
         psi = self._operand(psi, torch.complex64, (self.ptheta, self.nz, self.n), "psi")
         scan = self._operand(scan, torch.float32, (self.ptheta, self.nscan, 2), "scan")
         probe = self._operand(probe, torch.complex64, (self.ptheta, self.nprb, self.nprb), "probe")
-        farplane = torch.empty((self.ptheta, self.nscan, self.ndet, self.ndet),
-                               dtype=torch.complex64, device=psi.device)
+        if out is None:
+            farplane = torch.empty((self.ptheta, self.nscan, self.ndet, self.ndet),
+                                   dtype=torch.complex64, device=psi.device)
+        else:
+            farplane = self._operand(out, torch.complex64, (self.ptheta, self.nscan, self.ndet, self.ndet), "out")
+            assert farplane is out, "out must be contiguous"
         self._note_scan(scan)
         nat.check(nat.fwd(self._h, _ptr(farplane), _ptr(psi), _ptr(scan), _ptr(probe), _stream()))
         return farplane
 
-    def adj(self, farplane, scan, probe):
-        """Adjoint ptychography transform (Q*F*)."""
+    def adj(self, farplane, scan, probe, out=None):
+        """Adjoint ptychography transform (Q*F*).  ``out``: optional object tensor (zeroed here, ptycho.py:102)."""
         farplane = self._operand(farplane, torch.complex64,
                                  (self.ptheta, self.nscan, self.ndet, self.ndet), "farplane")
         scan = self._operand(scan, torch.float32, (self.ptheta, self.nscan, 2), "scan")
         probe = self._operand(probe, torch.complex64, (self.ptheta, self.nprb, self.nprb), "probe")
-        psi = torch.zeros((self.ptheta, self.nz, self.n), dtype=torch.complex64,
-                          device=farplane.device)
+        if out is None:
+            psi = torch.zeros((self.ptheta, self.nz, self.n), dtype=torch.complex64,
+                              device=farplane.device)
+        else:
+            psi = self._operand(out, torch.complex64, (self.ptheta, self.nz, self.n), "out")
+            assert psi is out, "out must be contiguous"
+            psi.zero_()
         self._note_scan(scan)
         nat.check(nat.adj(self._h, _ptr(psi), _ptr(farplane), _ptr(scan), _ptr(probe), 0, _stream()))
         return psi
