@@ -261,7 +261,9 @@ __global__ __launch_bounds__(ColCfg<N>::NT) void k_cols_gatherwin(const ColArgs 
     constexpr int WC = WinCfg<N>::WC, H = WinCfg<N>::H;
     constexpr int R0 = P::radix(0), RL = P::radix(LAST), NsL = P::ns(LAST);
     __shared__ c32 lds[SPLIT ? 1 : N * C];
-    __shared__ c32 win[H * WC];
+    // window rows are addressed modulo H; row H mirrors row 0, so the tap of the row below never wraps and both rows
+    // of a bilinear patch are read from one base address with immediate offsets (no address arithmetic for the second)
+    __shared__ c32 win[(H + 1) * WC];
 
     const int tid = threadIdx.x;
     const int c = tid % C, j0 = tid / C;
@@ -280,7 +282,7 @@ __global__ __launch_bounds__(ColCfg<N>::NT) void k_cols_gatherwin(const ColArgs 
     F fft;
     if (NM == 1) fft.init(j0, a.table);
     else for (int o = tid; o < N; o += NT) wtab[o] = a.table[o];
-    for (int o = tid; o < H * WC; o += NT) win[o] = zero;
+    for (int o = tid; o < (H + 1) * WC; o += NT) win[o] = zero;
 
     // FWD: c * probe strip in step-0 slot order (zero on padding -> masks the gather);
     // ADJ_PRB: gradient accumulators in natural order m (row j0 + m*T)
@@ -377,7 +379,9 @@ __global__ __launch_bounds__(ColCfg<N>::NT) void k_cols_gatherwin(const ColArgs 
                     const int X = X0 + col;
                     const bool inb = Y < ge.nz && X >= 0 && X < ge.n;
                     const c32 val = ft[inb ? ((size_t)Y * ge.n + X) : 0];
-                    win[(Y % H) * WC + col] = inb ? val : zero;
+                    const int ws = (Y % H) * WC + col;
+                    win[ws] = inb ? val : zero;
+                    if (ws < WC) win[H * WC + ws] = inb ? val : zero;   // mirror of row 0
                 }
             }
             Yhi = Rb;
@@ -385,7 +389,10 @@ __global__ __launch_bounds__(ColCfg<N>::NT) void k_cols_gatherwin(const ColArgs 
         return st;
     };
     auto prepare_commit = [&]() {
-        if (pre_slot >= 0) win[pre_slot] = pre_val;
+        if (pre_slot >= 0) {
+            win[pre_slot] = pre_val;
+            if (pre_slot < WC) win[H * WC + pre_slot] = pre_val;   // mirror of row 0
+        }
     };
     auto prepare = [&](int k, int kend) -> St {
         St st = prepare_issue(k, kend);
@@ -464,10 +471,8 @@ __global__ __launch_bounds__(ColCfg<N>::NT) void k_cols_gatherwin(const ColArgs 
             for (int m = 0; m < E; ++m) {
                 const int iy = j0 + m * T - ge.pad;
                 const bool ok = col_ok && iy >= 0 && iy < ge.nprb;
-                const int s1 = slot + 1 == H ? 0 : slot + 1;
                 const c32* r0 = win + slot * WC + colw;
-                const c32* r1 = win + s1 * WC + colw;
-                const c32 patch = r0[0] * w00 + r0[1] * w01 + r1[0] * w10 + r1[1] * w11;   // kernels.cu:84-91
+                const c32 patch = r0[0] * w00 + r0[1] * w01 + r0[WC] * w10 + r0[WC + 1] * w11;   // kernels.cu:84-91
                 const c32 term = cmulc(nat[m], patch);
                 pr[m] += ok ? term : zero;
                 slot += T;
@@ -514,10 +519,8 @@ __global__ __launch_bounds__(ColCfg<N>::NT) void k_cols_gatherwin(const ColArgs 
         const int colw = st.Xa - X0 + c;
         int slot0 = (q.sy + j0 - ge.pad + 2 * H) % H;
         auto patch_at = [&](int slot) {
-            const int s1 = slot + 1 == H ? 0 : slot + 1;
             const c32* r0 = win + slot * WC + colw;
-            const c32* r1 = win + s1 * WC + colw;
-            return r0[0] * w00 + r0[1] * w01 + r1[0] * w10 + r1[1] * w11;   // kernels.cu:97-104
+            return r0[0] * w00 + r0[1] * w01 + r0[WC] * w10 + r0[WC + 1] * w11;   // kernels.cu:97-104 (row H mirrors row 0)
         };
 
         c32 v[E];
