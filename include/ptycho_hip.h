@@ -176,10 +176,12 @@ int ptycho_cg_zoom(ptycho_handle h, const void* image_product, const void* best,
  *                         grad <- adj (raw, not yet divided by max|probe|^2).   all-reduce: grad
  *   ptycho_cg_obj_dir     grad /= max|probe|^2 (:356); Dai-Yuan dpsi, grad0 <- grad (:366-373); slot 1 <- column
  *                         pass of fwd(dpsi, probe); first line-search pass (:383-393).
- *                                                                    all-reduce: state[PTYCHO_ST_COSTS .. +68)
+ *                                                                    all-reduce: state[PTYCHO_ST_COSTS .. +119)
  *   ptycho_cg_ls_next     decide on the pass just reduced (line_search_sqr, :253-281); pass = 1, 2, 3: issue the next
  *                         pass (16, 32, 64 step lengths; each returns at once when the search is already
- *                         resolved) -> all-reduce state[COSTS..] again; pass = 4: decide only.  The accepted
+ *                         resolved) -> all-reduce state[COSTS..] again; pass = 4: decide only.  pass = 5: issue ALL
+ *                         remaining step lengths (112) as one pass, to be followed by pass = 4 -- two collectives per
+ *                         search instead of four for a multi-GPU caller.  The accepted
  *                         step length times 0.5 lands in state[GAMMA_PSI] (which = 0) / state[GAMMA_PRB] (which = 1).
  *   ptycho_cg_obj_finish  i > 0: position correction (:398-403; needs the zoom factors of ptycho_cg_zoom), scan[0] += shifts;
  *                         psi += gamma dpsi (:405)
@@ -199,8 +201,8 @@ enum {
     PTYCHO_ST_LS_GAMMA0 = 14, PTYCHO_ST_LS_NCAND = 15, PTYCHO_ST_LS_NGROUPS = 16, PTYCHO_ST_LS_TRIED = 17,
     PTYCHO_ST_LS_RESOLVED = 18, PTYCHO_ST_LS_FAILED = 19,
     PTYCHO_ST_HINT = 20,                        /* [2] accepted index of the last object / probe search (seed with 14) */
-    PTYCHO_ST_COSTS = 24,                       /* 4 groups x (16 step lengths + f(p1)) */
-    PTYCHO_CG_STATE_WORDS = 128
+    PTYCHO_ST_COSTS = 24,                       /* 7 groups x (16 step lengths + f(p1)) */
+    PTYCHO_CG_STATE_WORDS = 160
 };
 int ptycho_cg_obj_begin(ptycho_handle h, double* state, const void* psi, const void* scan, const void* prb,
                         const void* data, void* stream);

@@ -14,7 +14,7 @@
 //   k_cg_add_shifts    scan[0] += shifts                                           (ptycho.py:403)
 #pragma once
 
-constexpr int kLsGroupsMax = 4;   // a line-search pass prices up to 4 groups of 16 step lengths
+constexpr int kLsGroupsMax = 7;   // a line-search pass prices up to 7 groups of 16 step lengths
 
 __global__ void k_cg_scale_probe(c32* __restrict__ prb, const long long n, const double* __restrict__ st) {
     const float s = (float)st[PTYCHO_ST_A] / (float)st[PTYCHO_ST_B];   // float32, as ptycho.py:344 computes it
@@ -159,7 +159,7 @@ __global__ void k_cg_ls_decide(double* __restrict__ st, const int which, const i
         }
         if (!done) tried += ncand;
     }
-    if (!done && next_ngroups == 0) {   // cannot happen with 2..16 + 16 + 32 + 64 step lengths (2^-106 < 1e-32); fail safe
+    if (!done && next_ngroups == 0) {   // cannot happen with 2..16 + 16 + 32 + 64 (or 2..16 + 112) step lengths (2^-106 < 1e-32); fail safe
         st[gamma_word] = 0.0;
         st[PTYCHO_ST_LS_FAILED] += 1.0;
         done = true;

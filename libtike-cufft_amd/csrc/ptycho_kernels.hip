@@ -1229,10 +1229,11 @@ int ptycho_cg_obj_dir(ptycho_handle h, double* state, int first, const void* sca
 int ptycho_cg_ls_next(ptycho_handle h, double* state, int which, int pass, const void* data, int use_ab, void* stream) {
     int rc = check_stage(h, state);
     if (rc) return rc;
-    if (which < 0 || which > 1 || pass < 1 || pass > 4 || !data) return fail(PTYCHO_ERR_ARG, "bad line-search stage");
+    if (which < 0 || which > 1 || pass < 1 || pass > 5 || !data) return fail(PTYCHO_ERR_ARG, "bad line-search stage");
     hipStream_t st = (hipStream_t)stream;
-    // passes: <= 16 step lengths (sized from the last accepted index), then 16, 32, 64 more: 2^-106 < 1e-32 is covered
-    const int next_groups = pass == 1 ? 1 : (pass == 2 ? 2 : (pass == 3 ? 4 : 0));
+    // passes: <= 16 step lengths (sized from the last accepted index), then 16, 32, 64 more: 2^-106 < 1e-32 is covered.
+    // pass 5 (for callers that pay a collective per pass): everything that is left, 112 step lengths, at once.
+    const int next_groups = pass == 1 ? 1 : (pass == 2 ? 2 : (pass == 3 ? 4 : (pass == 5 ? kLsGroupsMax : 0)));
     hipLaunchKernelGGL(k_cg_ls_decide, dim3(1), dim3(1), 0, st, state, which,
                        which == 0 ? (int)PTYCHO_ST_GAMMA_PSI : (int)PTYCHO_ST_GAMMA_PRB, next_groups);
     HIP_TRY(hipGetLastError());

@@ -75,8 +75,8 @@ cg_prb_dir = _sig("ptycho_cg_prb_dir", _i, _vp, _vp, _i, _d, _d, _vp, _vp, _vp, 
 cg_prb_finish = _sig("ptycho_cg_prb_finish", _i, _vp, _vp, _vp, _vp, _vp)
 #: word offsets of the device-resident CG state (enum PTYCHO_ST_* in include/ptycho_hip.h)
 ST_A, ST_B, ST_COST, ST_COST2 = 0, 1, 2, 3
-ST_GAMMA_PSI, ST_GAMMA_PRB, ST_LS_FAILED, ST_HINT, ST_COSTS, ST_WORDS = 12, 13, 19, 20, 24, 128
-ST_NCOSTS = 4 * 17
+ST_GAMMA_PSI, ST_GAMMA_PRB, ST_LS_FAILED, ST_HINT, ST_COSTS, ST_WORDS = 12, 13, 19, 20, 24, 160
+ST_NCOSTS = 7 * 17
 profile = _sig("ptycho_profile", _i, _vp, _i)
 profile_read = _sig("ptycho_profile_read", _i, _vp, ctypes.POINTER(ctypes.c_double),
                     ctypes.POINTER(_ll), _i)

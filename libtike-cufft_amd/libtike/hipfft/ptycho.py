@@ -568,6 +568,7 @@ class CGPtychoSolver(PtychoHIP):
         self.fused = True      # gaussian loops through the fused CG-stage kernels
         self.native = True     # single-mode loop sequenced by the native stage calls (no host round trips)
         self._nscan_all = None
+        self.ls_two_pass = None  # native line search in two passes (<= 16, then 112 step lengths); None: with a group only
 
     # -- distributed glue ----------------------------------------------------
     def _allreduce(self, t):
@@ -709,9 +710,12 @@ class CGPtychoSolver(PtychoHIP):
             gprb, gprb0, dprb = (torch.zeros_like(probe[:, 0]) for _ in range(3))
         nscan_total = float(self._nscan_total())
         dist_on = self.group is not None
+        two_pass = dist_on if self.ls_two_pass is None else bool(self.ls_two_pass)
 
         def line_search(which, use_ab, S):
-            for p in (1, 2, 3, 4):
+            # one GPU: 16 + 32 + 64 more step lengths in passes that return at once when resolved; with a
+            # process group every pass costs a collective, so the second one prices all that is left
+            for p in ((5, 4) if two_pass else (1, 2, 3, 4)):
                 if dist_on:
                     self._allreduce(costs)
                 nat.check(nat.cg_ls_next(h, sp, which, p, _ptr(data), use_ab, S))

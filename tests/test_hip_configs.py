@@ -130,7 +130,8 @@ def test_cg_full_size_properties(pt):
     (2) the fused loop equals the statement-by-statement loop (HIP operators + torch
         elementwise, i.e. the reference's expressions) over the first 3 iterations:
         identical step sizes, cost within 1e-4, psi within 2e-4;
-    (3) started at the true object the gradient vanishes: psi does not move."""
+    (3) started at the true object the gradient vanishes: psi does not move;
+    (4) the one-GPU and the multi-GPU line-search schedules accept the same step lengths."""
     import torch
     p, psi_true, scan, probe = _cfg2_device_problem(torch)
     with pt.CGPtychoSolver(4096, 256, 256, 1, 768, 768) as slv:
@@ -162,6 +163,26 @@ def test_cg_full_size_properties(pt):
         slv.fused = True
         got = slv.run(data, psi_true.clone(), scan.clone(), probe.clone(), piter=1)
         assert float(torch.abs(got["psi"] - psi_true).max()) < 1e-4
+
+        # (4) the two line-search schedules of the native loop (passes of <=16, 16, 32, 64 step lengths on one GPU;
+        # <=16, 112 with a process group, one collective per pass) accept the same steps.  From the flat start the
+        # first searches of this problem go far beyond the first 16 step lengths, where the schedules differ.
+        smooth = torch.as_tensor(np.ascontiguousarray(p["probe"][:, None]), device="cuda")   # bench.py's probe
+        data = (torch.abs(slv.fwd(psi_true, scan, smooth[:, 0])) ** 2).contiguous()
+        # deep searches decide between float32 costs that differ in the last digits, so the float-atomic adjoint's
+        # run-to-run rounding noise can move an accepted index; the fixed-point adjoints take that out
+        slv.set_deterministic(True)
+        res = []
+        for two in (False, True):
+            slv.ls_two_pass = two
+            slv.history = []
+            r = slv.run(data, torch.ones_like(psi_true), scan.clone(), smooth.clone(), piter=4, recover_prb=True)
+            res.append((r["psi"].clone(), list(slv.history)))
+            del r
+        (pa, ha), (pb, hb) = res
+        assert min(h[1] for h in ha) < 2.0 ** -18, ha
+        check_history(ha, hb)
+        assert float(torch.abs(pa - pb).max() / torch.abs(pb).max()) < 2e-4
 
 
 def _dot(a, b, step=1024):
