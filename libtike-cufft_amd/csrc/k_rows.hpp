@@ -195,8 +195,15 @@ struct RowFusedArgs {
     const double* gamma_dev;
 };
 
+// Waves per SIMD the register allocation must leave room for.  Left alone the compiler takes 270..310 registers
+// (VGPR + AGPR) for the two-input stages, i.e. ONE wave per SIMD, and these kernels are bound by their VALU /
+// latency chains: two waves per SIMD (<= 256 registers) took the ndet = 256 line search from 2.0 to 1.3 ms.
 template <int N, int EP>
-__global__ __launch_bounds__(256) void k_rows_fused(const RowFusedArgs a) {
+constexpr int fused_min_waves() {
+    return (N <= 512 && (EP == EP_LINESEARCH || EP == EP_LINESEARCH_M || EP == EP_PROJECT || EP == EP_CROSS)) ? 2 : 1;
+}
+template <int N, int EP>
+__global__ __launch_bounds__(256, (fused_min_waves<N, EP>())) void k_rows_fused(const RowFusedArgs a) {
     using P = Plan<N>;
     using F = Fft<P, -1>;
     using L = RowLds<N>;
@@ -207,11 +214,21 @@ __global__ __launch_bounds__(256) void k_rows_fused(const RowFusedArgs a) {
     __shared__ c32 lds[P::NSTEP > 1 ? B * L::FS : 1];
     __shared__ double red[4 * NACC];
     __shared__ c32 stash[(EP == EP_CROSS || EP == EP_LINESEARCH_M) ? E * 256 : 1];
+    // three-step plans at two waves per SIMD: the 2 x 16 inter-step twiddles do not stay in registers across the
+    // batch loop (64 VGPRs); each step re-reads its set from an LDS copy of the table (Fft::init_step)
+    constexpr bool TWLDS = P::NSTEP > 2 && fused_min_waves<N, EP>() > 1;
+    __shared__ c32 wtab[TWLDS ? N : 1];
 
     const int tid = threadIdx.x;
     const int f = tid / T, j0 = tid % T;
+    int jz = j0;   // TWLDS: made opaque once per batch, which keeps the twiddle reads inside the batch loop
     F fft;
-    fft.init(j0, a.table);
+    if constexpr (TWLDS) {
+        for (int o = tid; o < N; o += 256) wtab[o] = a.table[o];
+        __syncthreads();
+    } else {
+        fft.init(j0, a.table);
+    }
     const c32 zero = c32{0.0f, 0.0f};
     float acc[NACC];
     c32 acc2[LS ? NACC : 1];   // line search: even / odd pixel partial sums
@@ -249,11 +266,13 @@ __global__ __launch_bounds__(256) void k_rows_fused(const RowFusedArgs a) {
             fft.template load<1>(v, j0, [&](int i) { return lds[L::at(f, i)]; });
             if (P::NSTEP > 2) {
                 __syncthreads();
+                if constexpr (TWLDS) fft.template init_step<1>(jz, wtab);
                 fft.template compute<1>(v);
                 fft.template store<1>(v, j0, [&](int i, c32 val) { lds[L::at(f, i)] = val; });
                 __syncthreads();
                 fft.template load<2>(v, j0, [&](int i) { return lds[L::at(f, i)]; });
             }
+            if constexpr (TWLDS) fft.template init_step<LAST>(jz, wtab);
             fft.template compute<LAST>(v);
             __syncthreads();   // lds free for the next transform
         }
@@ -272,6 +291,7 @@ __global__ __launch_bounds__(256) void k_rows_fused(const RowFusedArgs a) {
     for (long long batch = blockIdx.x; batch < nb; batch += gridDim.x) {
         const long long r = batch * B + f;
         const bool ok = r < a.nrows;
+        if constexpr (TWLDS) asm volatile("" : "+v"(jz));
         // addresses = wave-uniform batch base (scalar registers) + 32-bit per-thread offset: the
         // loads / stores take the saddr form and no 64-bit address lives in a VGPR
         const size_t boff = (size_t)batch * B * N;
@@ -313,11 +333,13 @@ __global__ __launch_bounds__(256) void k_rows_fused(const RowFusedArgs a) {
                 fft.template load<1>(v, j0, [&](int i) { return lds[L::at(f, i)]; });
                 if (P::NSTEP > 2) {
                     __syncthreads();
+                    if constexpr (TWLDS) fft.template init_step<1>(jz, wtab);
                     fft.template compute_rev<1>(v);
                     fft.template store<1>(v, j0, [&](int i, c32 val) { lds[L::at(f, i)] = val; });
                     __syncthreads();
                     fft.template load<2>(v, j0, [&](int i) { return lds[L::at(f, i)]; });
                 }
+                if constexpr (TWLDS) fft.template init_step<LAST>(jz, wtab);
                 fft.template compute_rev<LAST>(v);
             }
             fft.template store<LAST>(v, j0, [&](int i, c32 val) {
@@ -384,11 +406,13 @@ __global__ __launch_bounds__(256) void k_rows_fused(const RowFusedArgs a) {
                 fft.template load<1>(v, j0, [&](int i) { return lds[L::at(f, i)]; });
                 if (P::NSTEP > 2) {
                     __syncthreads();
+                    if constexpr (TWLDS) fft.template init_step<1>(jz, wtab);
                     fft.template compute_rev<1>(v);
                     fft.template store<1>(v, j0, [&](int i, c32 val) { lds[L::at(f, i)] = val; });
                     __syncthreads();
                     fft.template load<2>(v, j0, [&](int i) { return lds[L::at(f, i)]; });
                 }
+                if constexpr (TWLDS) fft.template init_step<LAST>(jz, wtab);
                 fft.template compute_rev<LAST>(v);
             }
             fft.template store<LAST>(v, j0, [&](int i, c32 val) {
