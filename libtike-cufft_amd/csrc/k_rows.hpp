@@ -198,9 +198,15 @@ struct RowFusedArgs {
 // Waves per SIMD the register allocation must leave room for.  Left alone the compiler takes 270..310 registers
 // (VGPR + AGPR) for the two-input stages, i.e. ONE wave per SIMD, and these kernels are bound by their VALU /
 // latency chains: two waves per SIMD (<= 256 registers) took the ndet = 256 line search from 2.0 to 1.3 ms.
+// (The plain row pass k_rows<512> is the opposite case: forced from 2 to 3 or 4 waves per SIMD, with the twiddles
+// in registers or re-read from LDS, it went 3.24 -> 3.41 / 3.43 ms; it keeps the compiler's 185 registers.)
 template <int N, int EP>
 constexpr int fused_min_waves() {
-    return (N <= 512 && (EP == EP_LINESEARCH || EP == EP_LINESEARCH_M || EP == EP_PROJECT || EP == EP_CROSS)) ? 2 : 1;
+    return (N <= 512 && (EP == EP_LINESEARCH || EP == EP_LINESEARCH_M || EP == EP_PROJECT || EP == EP_CROSS)) ? 2
+           : (N == 512 && (EP == EP_STATS || EP == EP_STATS_M)) ? 3 : 1;
+}
+template <>
+constexpr int fused_min_waves<256, EP_STATS>() { return 4;   // 0.527 -> 0.505 ms (PROJECT at three waves spills: 1.03 -> 1.31)
 }
 template <int N, int EP>
 __global__ __launch_bounds__(256, (fused_min_waves<N, EP>())) void k_rows_fused(const RowFusedArgs a) {

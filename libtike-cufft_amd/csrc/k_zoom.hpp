@@ -207,7 +207,7 @@ __global__ void k_zoom_prepare(const unsigned long long* __restrict__ best, cons
 
 
 template <int NT>
-__global__ __launch_bounds__(NT) void k_zoom_mfma(const c32* __restrict__ ip, const double2* __restrict__ px,
+__global__ __launch_bounds__(NT, (NT == 256 ? 3 : 1)) void k_zoom_mfma(const c32* __restrict__ ip, const double2* __restrict__ px,
                                                   const double2* __restrict__ py, const double* __restrict__ vt,
                                                   const double* __restrict__ lz, const int N, const int nc,
                                                   const int ups, int* __restrict__ out,
