@@ -193,6 +193,9 @@ struct RowFusedArgs {
     // costs of group grp to st[PTYCHO_ST_COSTS + 17 grp ...]; EP_CROSS: gamma = *gamma_dev.
     double* st;
     const double* gamma_dev;
+    // EP_PROJECT: if set, max |out| (float bits in the low word, as k_cg_absmax leaves it) -- the deterministic
+    // adjoint that follows sizes its fixed point from it and skips its own pass over the slot
+    double* maxword;
 };
 
 // Waves per SIMD the register allocation must leave room for.  Left alone the compiler takes 270..310 registers
@@ -222,7 +225,7 @@ __global__ __launch_bounds__(256, (fused_min_waves<N, EP>())) void k_rows_fused(
     __shared__ c32 stash[(EP == EP_CROSS || EP == EP_LINESEARCH_M) ? E * 256 : 1];
     // three-step plans at two waves per SIMD: the 2 x 16 inter-step twiddles do not stay in registers across the
     // batch loop (64 VGPRs); each step re-reads its set from an LDS copy of the table (Fft::init_step)
-    constexpr bool TWLDS = P::NSTEP > 2 && fused_min_waves<N, EP>() > 1;
+    constexpr bool TWLDS = (P::NSTEP > 2 && fused_min_waves<N, EP>() > 1) || (N == 256 && (EP == EP_LINESEARCH || EP == EP_LINESEARCH_M));
     __shared__ c32 wtab[TWLDS ? N : 1];
 
     const int tid = threadIdx.x;
@@ -251,6 +254,7 @@ __global__ __launch_bounds__(256, (fused_min_waves<N, EP>())) void k_rows_fused(
         sinv = bf / af;
     }
 
+    float vmax2 = 0.0f;   // EP_PROJECT with maxword: running max |out|^2 of this thread
     float gamma0 = a.gamma0;
     int ncand = a.ncand, ngroups = 1;
     double* sums = a.sums;
@@ -421,6 +425,10 @@ __global__ __launch_bounds__(256, (fused_min_waves<N, EP>())) void k_rows_fused(
                 if constexpr (TWLDS) fft.template init_step<LAST>(jz, wtab);
                 fft.template compute_rev<LAST>(v);
             }
+            if (a.maxword && ok) {
+#pragma unroll
+                for (int m = 0; m < E; ++m) vmax2 = fmaxf(vmax2, v[m].x * v[m].x + v[m].y * v[m].y);
+            }
             fft.template store<LAST>(v, j0, [&](int i, c32 val) {
                 if (ok) __builtin_nontemporal_store(val, a.out + boff + (fN + (unsigned)i));
             });
@@ -515,6 +523,12 @@ __global__ __launch_bounds__(256, (fused_min_waves<N, EP>())) void k_rows_fused(
     }
     if (EP == EP_CROSS) return;
     if (EP == EP_STATS_M && !a.sums) return;
+    if (EP == EP_PROJECT && a.maxword) {   // one atomicMax per wave (non-negative floats order like unsigned integers)
+        float m = vmax2;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_down(m, off, 64));
+        if ((tid & 63) == 0) atomicMax(reinterpret_cast<unsigned*>(a.maxword), __float_as_uint(sqrtf(m) * 1.0000002f));
+    }
     // ---- block reduction (float partials -> double), one atomic per value per workgroup
     const int lane = tid & 63, wave = tid >> 6;
 #pragma unroll

@@ -80,6 +80,8 @@ struct ptycho_handle_s {
     int* sort_counts = nullptr;    // k_rank_positions: partial ranks [positions] + tickets [ceil(positions / 256)], self-clearing
     static constexpr int kSlots = 2 * kMaxModes;
     c32* work[kSlots] = {};   // CG work buffers (column-pass intermediates), all positions; 0/1 + per-mode pairs
+    double* slot_maxw = nullptr;      // [kSlots] max |slot content| left by the PROJECT stage (deterministic option)
+    bool slot_max_ok[kSlots] = {};    // ... and whether that word describes what the slot holds now
     void* zoom_phase = nullptr;           // registration: per-pattern phases + whole-pixel shifts
     c32* reg_ip = nullptr;                // native CG loop: image product of the registration [positions][ndet][ndet]
     unsigned long long* reg_best = nullptr;   // whole-pixel peaks [positions]
@@ -336,7 +338,8 @@ int do_fwd(ptycho_handle h, c32* g, const c32* f, const float* scan, const c32* 
 
 
 // ---- deterministic adjoints (option "deterministic"): set-up before / fold-in after the column pass ----
-int det_begin(ptycho_handle h, ColArgs& ca, const c32* gsrc, long long gcount, const c32* other, long long ocount, int flg, hipStream_t st) {
+int det_begin(ptycho_handle h, ColArgs& ca, const c32* gsrc, long long gcount, const c32* other, long long ocount, int flg, hipStream_t st,
+              const double* known_gmax = nullptr) {   // known_gmax: max |gsrc| is already on the device (k_cg_absmax format)
     const Geom& ge = h->ge;
     const size_t nobj = (size_t)ge.ptheta * ge.nz * ge.n, nprb = (size_t)ge.ptheta * ge.nprb * ge.nprb;
     if (!h->det_acc) {
@@ -349,14 +352,14 @@ int det_begin(ptycho_handle h, ColArgs& ca, const c32* gsrc, long long gcount, c
     HIP_TRY(hipMemsetAsync(h->det_words, 0, 2 * sizeof(double), st));
     long long gg = (gcount + 255) / 256;
     if (gg > (long long)h->n_cu * 16) gg = (long long)h->n_cu * 16;
-    hipLaunchKernelGGL(k_cg_absmax, dim3((unsigned)gg), dim3(256), 0, st, gsrc, gcount, h->det_words);
+    if (!known_gmax) hipLaunchKernelGGL(k_cg_absmax, dim3((unsigned)gg), dim3(256), 0, st, gsrc, gcount, h->det_words);
     long long go = (ocount + 255) / 256;
     if (go > (long long)h->n_cu * 4) go = (long long)h->n_cu * 4;
     hipLaunchKernelGGL(k_cg_absmax, dim3((unsigned)go), dim3(256), 0, st, other, ocount, h->det_words + 1);
     // additions per element: every position of an angle may touch it, four bilinear taps (object) / once (probe)
     const long long nadd = flg == 0 ? 4ll * ge.nscan : (long long)ge.nscan;
-    hipLaunchKernelGGL(k_det_scale, dim3(1), dim3(1), 0, st, (const double*)h->det_words, (const double*)(h->det_words + 1), ge.ndet, nadd,
-                       h->det_scale);
+    hipLaunchKernelGGL(k_det_scale, dim3(1), dim3(1), 0, st, known_gmax ? known_gmax : (const double*)h->det_words,
+                       (const double*)(h->det_words + 1), ge.ndet, nadd, h->det_scale);
     HIP_TRY(hipGetLastError());
     ca.det_acc = h->det_acc;
     ca.det_scale = h->det_scale;
@@ -466,14 +469,27 @@ int do_fft2(ptycho_handle h, c32* dst, const c32* src, long long nbatch, int dir
 inline int slot_a(ptycho_handle h, int k) { return h->compact_modes ? k : 2 * k; }
 inline int slot_b(ptycho_handle h, int k) { return h->compact_modes ? h->compact_modes : 2 * k + 1; }
 inline bool slot_ready(ptycho_handle h, int slot) { return slot >= 0 && slot < ptycho_handle_s::kSlots && h->work[slot]; }
-int ensure_work(ptycho_handle h, int slot) {
+int ensure_work(ptycho_handle h, int slot) {   // called by every stage that is about to write the slot
     if (slot < 0 || slot >= ptycho_handle_s::kSlots) return fail(PTYCHO_ERR_ARG, "work slot out of range");
+    h->slot_max_ok[slot] = false;
     if (!h->work[slot]) {
         // kMaxModes spare tiles: the M chunk parts of the shared slot of the compact layout take M ceil(total / M) tiles
         const size_t total = (size_t)h->ge.ptheta * h->ge.nscan + kMaxModes;
         HIP_TRY(hipMalloc((void**)&h->work[slot], total * h->ge.ndet * h->ge.ndet * sizeof(c32)));
         HIP_TRY(hipMemset(h->work[slot], 0, total * h->ge.ndet * h->ge.ndet * sizeof(c32)));
     }
+    return PTYCHO_OK;
+}
+
+// deterministic option: the PROJECT stage leaves max |dst slot| on the device for the adjoint column pass that follows
+int project_maxword(ptycho_handle h, int dst_slot, RowFusedArgs& a, hipStream_t st) {
+    if (!h->deterministic) return PTYCHO_OK;
+    if (!h->slot_maxw) {
+        HIP_TRY(hipMalloc((void**)&h->slot_maxw, ptycho_handle_s::kSlots * sizeof(double)));
+        HIP_TRY(hipMemset(h->slot_maxw, 0, ptycho_handle_s::kSlots * sizeof(double)));
+    }
+    HIP_TRY(hipMemsetAsync(h->slot_maxw + dst_slot, 0, sizeof(double), st));
+    a.maxword = h->slot_maxw + dst_slot;
     return PTYCHO_OK;
 }
 
@@ -517,7 +533,8 @@ int do_cg_adj_cols(ptycho_handle h, int slot, c32* f, const float* scan, c32* pr
     if (h->deterministic) {
         if (!window) return fail(PTYCHO_ERR_ARG, "option deterministic needs the windowed adjoint kernels (ndet <= 512)");
         rc = det_begin(h, ca, h->work[slot], total * N * N, flg == 0 ? prb : f,
-                       flg == 0 ? (long long)ge.ptheta * ge.nprb * ge.nprb : (long long)ge.ptheta * ge.nz * ge.n, flg, st);
+                       flg == 0 ? (long long)ge.ptheta * ge.nprb * ge.nprb : (long long)ge.ptheta * ge.nz * ge.n, flg, st,
+                       h->slot_max_ok[slot] ? h->slot_maxw + slot : nullptr);
         if (rc) return rc;
     }
     if (flg == 0) {
@@ -680,6 +697,7 @@ int alloc_sort(ptycho_handle h) {
 }
 
 void release(ptycho_handle h) {
+    if (h->slot_maxw) { (void)hipFree(h->slot_maxw); h->slot_maxw = nullptr; }
     void* ptrs[] = {h->det_acc, h->det_scale, h->det_words, h->bs_chirp, h->bs_hfilt, h->table, h->scratch, h->order, h->sort_counts, h->zoom_phase, h->prbp, h->reg_ip, h->reg_best, h->reg_shifts};
     h->det_acc = nullptr; h->det_scale = nullptr; h->det_words = nullptr; h->zoom_phase = nullptr; h->prbp = nullptr; h->bs_chirp = nullptr; h->bs_hfilt = nullptr; h->reg_ip = nullptr; h->reg_best = nullptr; h->reg_shifts = nullptr;
     for (auto& w : h->work) { if (w) (void)hipFree(w); w = nullptr; }
@@ -946,6 +964,9 @@ int ptycho_cg_project(ptycho_handle h, int src_slot, int dst_slot, const void* d
     RowFusedArgs a{};
     a.s1 = h->work[src_slot]; a.out = h->work[dst_slot]; a.data = (const float*)data; a.sums = cost; a.ab = ab;
     hipStream_t st = (hipStream_t)stream;
+    rc = project_maxword(h, dst_slot, a, st);
+    if (rc) return rc;
+    h->slot_max_ok[dst_slot] = a.maxword != nullptr;
     PTY_DISPATCH(h->ge.ndet, (do_cg_rows<NN, EP_PROJECT>(h, a, st)));
 }
 
@@ -977,6 +998,9 @@ int ptycho_cg_project_multi(ptycho_handle h, int src_slot, int dst_slot, const v
     a.inten = (const float*)inten;
     a.first = slot_unscaled ? 1 : 0;
     hipStream_t st = (hipStream_t)stream;
+    rc = project_maxword(h, dst_slot, a, st);
+    if (rc) return rc;
+    h->slot_max_ok[dst_slot] = a.maxword != nullptr;
     PTY_DISPATCH(h->ge.ndet, (do_cg_rows<NN, EP_PROJECT>(h, a, st)));
 }
 
@@ -1066,6 +1090,7 @@ extern "C" int ptycho_cg_cross(ptycho_handle h, int slot1, int slot2, double gam
         return fail(PTYCHO_ERR_ARG, "work slot is empty");
     RowFusedArgs a{};
     a.s1 = h->work[slot1]; a.s2 = h->work[slot2]; a.out = h->work[slot2]; a.ip = (c32*)image_product;
+    h->slot_max_ok[slot2] = false;
     a.gamma0 = (float)gamma;
     hipStream_t st = (hipStream_t)stream;
     PTY_DISPATCH(h->ge.ndet, (do_cg_rows<NN, EP_CROSS>(h, a, st)));
@@ -1162,6 +1187,7 @@ template <int N>
 int do_cross_dev(ptycho_handle h, const double* gamma_dev, hipStream_t st) {
     RowFusedArgs a{};
     a.s1 = h->work[0]; a.s2 = h->work[1]; a.out = h->work[1]; a.ip = h->reg_ip; a.gamma_dev = gamma_dev;
+    h->slot_max_ok[1] = false;
     return do_cg_rows<N, EP_CROSS>(h, a, st);
 }
 int cross_dev(ptycho_handle h, const double* gamma_dev, hipStream_t st) {

@@ -98,6 +98,7 @@ class PtychoHIP:
         nat.check(nat.create(ctypes.byref(self._h), ntheta, nz, n, nscan,
                              detector_shape, probe_shape))
         self._device = torch.device("cuda", torch.cuda.current_device())
+        self._det = False      # option "deterministic" as set by set_deterministic()
 
     # read-only size attributes of the native object (swig/ptychofft.i:11-16)
     ptheta = property(lambda self: int(nat.get(self._h, 0)))
@@ -143,6 +144,7 @@ class PtychoHIP:
         """Adjoints accumulate in 64-bit fixed point (integer atomics): bitwise reproducible results
         (the reference's float ``atomicAdd``, kernels.cu:73-80,92-93, is not).  ndet <= 512."""
         nat.check(nat.set_option(self._h, b"deterministic", int(bool(on))))
+        self._det = bool(on)
 
     def set_fused(self, tiles=2):
         """ndet = 256: forward operator as one launch (``k_fwd_fused256``), ``tiles`` = 0 (off), 1 or 2."""
@@ -568,6 +570,7 @@ class CGPtychoSolver(PtychoHIP):
         self.fused = True      # gaussian loops through the fused CG-stage kernels
         self.native = True     # single-mode loop sequenced by the native stage calls (no host round trips)
         self._nscan_all = None
+        self.reproducible = True  # fused CG loops use the deterministic adjoints (same trajectory every run)
         self.ls_two_pass = None  # native line search in two passes (<= 16, then 112 step lengths); None: with a group only
 
     # -- distributed glue ----------------------------------------------------
@@ -1029,14 +1032,25 @@ class CGPtychoSolver(PtychoHIP):
         assert probe.ndim == 4, "probe needs 4 dimensions, not %d" % probe.ndim
         nmodes = probe.shape[1]
         pow2 = self.ndet >= 16 and (self.ndet & (self.ndet - 1)) == 0   # the fused CG stages use the power-of-two plans
-        if self.fused and model == "gaussian" and pow2:
-            if nmodes == 1:
-                zoom = self._native_ready()
-                if zoom is not None:
-                    return self._run_native(data, psi, scan, probe, piter, recover_prb, zoom)
-                return self._run_fused(data, psi, scan, probe, piter, recover_prb)
-            if nmodes <= 8:          # one pair of work slots per mode (ptycho_hip.h)
-                return self._run_fused_multi(data, psi, scan, probe, piter, recover_prb)
+        if self.fused and model == "gaussian" and pow2 and nmodes <= 8:
+            # The fused loops run on the deterministic adjoints unless told otherwise: with float atomics (the
+            # reference's kernels.cu:73-80) two runs of the same problem take different line-search paths -- near a
+            # flat start the accept / reject decisions sit on the last float32 digit of the cost -- and differ by
+            # +-10 % in time (tools/cg_variance.py).  In the loop the fixed-point scale comes from the projection
+            # stage, so this costs no extra pass.
+            det = self.reproducible and not self._det and self.ndet <= 512
+            if det:
+                nat.check(nat.set_option(self._h, b"deterministic", 1))
+            try:
+                if nmodes == 1:
+                    zoom = self._native_ready()
+                    if zoom is not None:
+                        return self._run_native(data, psi, scan, probe, piter, recover_prb, zoom)
+                    return self._run_fused(data, psi, scan, probe, piter, recover_prb)
+                return self._run_fused_multi(data, psi, scan, probe, piter, recover_prb)   # one pair of work slots per mode
+            finally:
+                if det:
+                    nat.check(nat.set_option(self._h, b"deterministic", 0))
         nscan_total = self._nscan_total()
 
         def minf(fpsi):
