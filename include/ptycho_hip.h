@@ -228,7 +228,8 @@ int ptycho_cg_prb_finish(ptycho_handle h, double* state, void* prb, const void* 
  * "split" (ndet = 256: 1 = one radix-16 step of the DFT over y runs in the row pass [default]);
  * "deterministic" (1 = the adjoints add their per-workgroup sums into a 64-bit fixed-point image with integer
  * atomics and fold it into the output once: bitwise reproducible for a given chunk / run partition, one extra read of
- * g for the scale; needs the windowed kernels, ndet <= 512; default 0: float atomics, as kernels.cu:73-80,92-93);
+ * g for the scale (none after ptycho_cg_project, which leaves max |slot| on the device); needs the windowed kernels,
+ * ndet <= 512; default 0: float atomics, as kernels.cu:73-80,92-93);
  * "compact_modes" (M = number of probe modes: compact slot layout + chunk-major position order, see above; 0 = slot pairs);
  * "fused" (ndet = 256: forward operator as ONE launch that keeps the column<->row intermediate on
  * the CU, k_fwd_fused256: 0 = off, 1 / 2 = one / two class tiles per pass).
