@@ -192,10 +192,11 @@ def main():
         return upd
 
     # ~0.3 s of untimed work first: an idle MI355X ramps its clocks over that long (tools/cg512.py), and the
-    # official warm-up of a few steps is only a few milliseconds
+    # official warm-up of a few steps is only a few milliseconds.  Local work only: the loop is bounded by each rank's
+    # own clock, so a collective inside it would be issued a different number of times per rank (deadlock).
     t_ramp = time.perf_counter()
     while time.perf_counter() - t_ramp < 0.4:
-        one_step()
+        slv.adj(slv.fwd(psi, scan, prb, out=g_buf), scan, prb, out=upd_buf)
         torch.cuda.synchronize()
 
     def fence():
@@ -291,13 +292,14 @@ def main():
         if dist and ngpu > 1 and R % ngpu == 0:
             try:
                 # strong scaling of the CG loop (BASELINE.json target: >= 6x at 8 GPUs): the SAME
-                # 4096-position problem of configs[1], raster rows [r R/N, (r+1) R/N) on rank r
+                # 4096-position problem of configs[1], raster columns [r R/N, (r+1) R/N) on rank r (column bands keep
+                # the runs of the windowed column kernels at full raster height: tools/cg_shard_shape.py, 1.33 vs 1.38 ms)
                 del data
                 Rr = R // ngpu
                 nz1, n1 = syn.object_size_for(R, R, step, nprb)
                 psi1 = torch.as_tensor(syn.random_object(nz1, n1, np.random.default_rng(1234)), device=dev)
-                scan1 = torch.as_tensor(syn.raster_scan(Rr, R, step, np.random.default_rng(99 + rank),
-                                                         y0=float(rank * Rr * step)), device=dev)
+                scan1 = torch.as_tensor(syn.raster_scan(R, Rr, step, np.random.default_rng(99 + rank),
+                                                         x0=float(rank * Rr * step)), device=dev)
                 s2 = pt.CGPtychoSolver(Rr * R, nprb, ndet, 1, nz1, n1, group=dist.group.WORLD)
                 s2.verbose = False
                 data1 = (torch.abs(s2.fwd(psi1, scan1, prb)) ** 2).contiguous()
