@@ -50,12 +50,6 @@ __global__ void k_pad_probe(const c32* __restrict__ prb, c32* __restrict__ out, 
     out[i] = ok ? prb[((size_t)t * ge.nprb + iy) * ge.nprb + ix] * cinv : c32{0.0f, 0.0f};
 }
 
-// LDS accesses of one wave are served in order; this only stops the compiler from moving them
-__device__ __forceinline__ void wave_lds_fence() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
 
 __device__ __forceinline__ c32 mul_mi(c32 a) { return c32{a.y, -a.x}; }   // a * (-i)
 __device__ __forceinline__ c32 mul_pi(c32 a) { return c32{-a.y, a.x}; }   // a * (+i)

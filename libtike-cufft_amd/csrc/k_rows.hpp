@@ -36,13 +36,13 @@ __global__ __launch_bounds__(256) void k_rows(const RowArgs a) {
         fft.template compute<0>(v);
         if (P::NSTEP > 1) {
             fft.template store<0>(v, j0, [&](int i, c32 val) { lds[L::at(f, i)] = val; });
-            __syncthreads();
+            row_sync<T>();
             fft.template load<1>(v, j0, [&](int i) { return lds[L::at(f, i)]; });
             if (P::NSTEP > 2) {
-                __syncthreads();
+                row_sync<T>();
                 fft.template compute<1>(v);
                 fft.template store<1>(v, j0, [&](int i, c32 val) { lds[L::at(f, i)] = val; });
-                __syncthreads();
+                row_sync<T>();
                 fft.template load<2>(v, j0, [&](int i) { return lds[L::at(f, i)]; });
             }
             fft.template compute<LAST>(v);
@@ -55,7 +55,7 @@ __global__ __launch_bounds__(256) void k_rows(const RowArgs a) {
             fft.template store<LAST>(v, j0, [&](int i, c32 val) {
                 if (ok && i >= a.wa && i < a.wb) drow[i] = val;
             });
-        if (P::NSTEP > 1) __syncthreads();
+        if (P::NSTEP > 1) row_sync<T>();
     }
 }
 
@@ -112,7 +112,7 @@ __global__ __launch_bounds__(256) void k_rows_split(const RowArgs a) {
             fft.template load<0>(v, j0, [&](int i) { return lds[L::at(f, i)]; });
             fft.template compute<0>(v);
             fft.template store<0>(v, j0, [&](int i, c32 val) { lds[L::at(f, i)] = val; });
-            __syncthreads();
+            row_sync<T>();   // exchange inside row f: the row's 16 threads are lanes of one wave
             fft.template load<1>(v, j0, [&](int i) { return lds[L::at(f, i)]; });
             fft.template compute<LAST>(v);
             c32* drow = dbase + (size_t)(jp + 16 * f) * N;
@@ -124,10 +124,10 @@ __global__ __launch_bounds__(256) void k_rows_split(const RowArgs a) {
             fft.template load<0>(v, j0, [&](int i) { return __builtin_nontemporal_load(srow + i); });
             fft.template compute<0>(v);
             fft.template store<0>(v, j0, [&](int i, c32 val) { lds[L::at(f, i)] = val; });
-            __syncthreads();
+            row_sync<T>();
             fft.template load<1>(v, j0, [&](int i) { return lds[L::at(f, i)]; });
             fft.template compute<LAST>(v);
-            __syncthreads();   // every exchange read is done before the rows are rewritten
+            row_sync<T>();   // every exchange read of row f is done before the row is rewritten
             fft.template store<LAST>(v, j0, [&](int i, c32 val) { lds[L::at(f, i)] = val; });
             __syncthreads();
             // ---- first radix-16 step of the IDFT over y, thread = column x -------------------
@@ -272,19 +272,19 @@ __global__ __launch_bounds__(256, (fused_min_waves<N, EP>())) void k_rows_fused(
         fft.template compute<0>(v);
         if (P::NSTEP > 1) {
             fft.template store<0>(v, j0, [&](int i, c32 val) { lds[L::at(f, i)] = val; });
-            __syncthreads();
+            row_sync<T>();
             fft.template load<1>(v, j0, [&](int i) { return lds[L::at(f, i)]; });
             if (P::NSTEP > 2) {
-                __syncthreads();
+                row_sync<T>();
                 if constexpr (TWLDS) fft.template init_step<1>(jz, wtab);
                 fft.template compute<1>(v);
                 fft.template store<1>(v, j0, [&](int i, c32 val) { lds[L::at(f, i)] = val; });
-                __syncthreads();
+                row_sync<T>();
                 fft.template load<2>(v, j0, [&](int i) { return lds[L::at(f, i)]; });
             }
             if constexpr (TWLDS) fft.template init_step<LAST>(jz, wtab);
             fft.template compute<LAST>(v);
-            __syncthreads();   // lds free for the next transform
+            row_sync<T>();   // lds free for the next transform
         }
         F::to_natural(v, nat);
     };
@@ -339,14 +339,14 @@ __global__ __launch_bounds__(256, (fused_min_waves<N, EP>())) void k_rows_fused(
             fft.template compute_rev<0>(v);
             if (P::NSTEP > 1) {
                 fft.template store<0>(v, j0, [&](int i, c32 val) { lds[L::at(f, i)] = val; });
-                __syncthreads();
+                row_sync<T>();
                 fft.template load<1>(v, j0, [&](int i) { return lds[L::at(f, i)]; });
                 if (P::NSTEP > 2) {
-                    __syncthreads();
+                    row_sync<T>();
                     if constexpr (TWLDS) fft.template init_step<1>(jz, wtab);
                     fft.template compute_rev<1>(v);
                     fft.template store<1>(v, j0, [&](int i, c32 val) { lds[L::at(f, i)] = val; });
-                    __syncthreads();
+                    row_sync<T>();
                     fft.template load<2>(v, j0, [&](int i) { return lds[L::at(f, i)]; });
                 }
                 if constexpr (TWLDS) fft.template init_step<LAST>(jz, wtab);
@@ -355,7 +355,7 @@ __global__ __launch_bounds__(256, (fused_min_waves<N, EP>())) void k_rows_fused(
             fft.template store<LAST>(v, j0, [&](int i, c32 val) {
                 if (ok) __builtin_nontemporal_store(val, a.out + boff + (fN + (unsigned)i));
             });
-            if (P::NSTEP > 1) __syncthreads();
+            if (P::NSTEP > 1) row_sync<T>();
             continue;
         }
 
@@ -412,14 +412,14 @@ __global__ __launch_bounds__(256, (fused_min_waves<N, EP>())) void k_rows_fused(
             fft.template compute_rev<0>(v);
             if (P::NSTEP > 1) {
                 fft.template store<0>(v, j0, [&](int i, c32 val) { lds[L::at(f, i)] = val; });
-                __syncthreads();
+                row_sync<T>();
                 fft.template load<1>(v, j0, [&](int i) { return lds[L::at(f, i)]; });
                 if (P::NSTEP > 2) {
-                    __syncthreads();
+                    row_sync<T>();
                     if constexpr (TWLDS) fft.template init_step<1>(jz, wtab);
                     fft.template compute_rev<1>(v);
                     fft.template store<1>(v, j0, [&](int i, c32 val) { lds[L::at(f, i)] = val; });
-                    __syncthreads();
+                    row_sync<T>();
                     fft.template load<2>(v, j0, [&](int i) { return lds[L::at(f, i)]; });
                 }
                 if constexpr (TWLDS) fft.template init_step<LAST>(jz, wtab);
@@ -432,7 +432,7 @@ __global__ __launch_bounds__(256, (fused_min_waves<N, EP>())) void k_rows_fused(
             fft.template store<LAST>(v, j0, [&](int i, c32 val) {
                 if (ok) __builtin_nontemporal_store(val, a.out + boff + (fN + (unsigned)i));
             });
-            if (P::NSTEP > 1) __syncthreads();
+            if (P::NSTEP > 1) row_sync<T>();
         } else if (EP == EP_LINESEARCH_M) {
             // multi-mode line search (ptycho.py:383-393 with the sums over k of :386-391): the terms
             // p1, p2, p3 are accumulated over the modes in registers, never stored

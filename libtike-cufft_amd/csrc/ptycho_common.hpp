@@ -117,3 +117,18 @@ __device__ __forceinline__ c32 bilerp(const c32* __restrict__ ft, int Y, int X, 
     }
     return f00 * wx0 * wy0 + f01 * q.fx * wy0 + f10 * wx0 * q.fy + f11 * q.fx * q.fy;
 }
+
+// LDS accesses of one wave are served in order; this only stops the compiler from moving them
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+// Synchronisation between the steps of ONE row transform in the row kernels: the T threads of a row exchange through
+// their own LDS row only, and for T <= 64 (N <= 1024) they are lanes of one wave -- no workgroup barrier is needed,
+// the waves of a workgroup run their rows independently.
+template <int T>
+__device__ __forceinline__ void row_sync() {
+    if constexpr (T <= 64 && 64 % T == 0) wave_lds_fence();
+    else __syncthreads();
+}
