@@ -183,12 +183,29 @@ def main():
     # the outputs are allocated once: the timed region measures the operators, not torch's caching allocator
     g_buf = torch.empty((1, nscan, ndet, ndet), dtype=torch.complex64, device=dev)
     upd_buf = torch.empty((1, nz, n), dtype=torch.complex64, device=dev)
+    # N > 1: the object update of step k is all-reduced (RCCL, its own stream) while step k + 1 computes -- two update
+    # buffers, a step waits for the reduction that last used its buffer.  Every reduction is finished inside the
+    # timed region (fence()).
+    upd_bufs = [upd_buf, torch.empty_like(upd_buf)] if dist else [upd_buf]
+    pending = [None, None]
+    step_no = [0]
+
+    def drain():
+        for b in (0, 1):
+            if pending[b] is not None:
+                pending[b].wait()
+                pending[b] = None
 
     def one_step():
+        b = step_no[0] & 1 if dist else 0
+        step_no[0] += 1
+        if pending[b] is not None:
+            pending[b].wait()
+            pending[b] = None
         g = slv.fwd(psi, scan, prb, out=g_buf)
-        upd = slv.adj(g, scan, prb, out=upd_buf)      # zero-fills upd_buf, as the reference's adj does (ptycho.py:102)
+        upd = slv.adj(g, scan, prb, out=upd_bufs[b])   # zero-fills its output, as the reference's adj does (ptycho.py:102)
         if dist:
-            dist.all_reduce(torch.view_as_real(upd))
+            pending[b] = dist.all_reduce(torch.view_as_real(upd), async_op=True)
         return upd
 
     # ~0.3 s of untimed work first: an idle MI355X ramps its clocks over that long (tools/cg512.py), and the
@@ -200,6 +217,7 @@ def main():
         torch.cuda.synchronize()
 
     def fence():
+        drain()
         torch.cuda.synchronize()
         if dist:
             dist.barrier()
