@@ -179,12 +179,15 @@ int ptycho_cg_zoom(ptycho_handle h, const void* image_product, const void* best,
  *                                                                    all-reduce: state[PTYCHO_ST_COSTS .. +119)
  *   ptycho_cg_ls_next     decide on the pass just reduced (line_search_sqr, :253-281); pass = 1, 2, 3: issue the next
  *                         pass (16, 32, 64 step lengths; each returns at once when the search is already
- *                         resolved) -> all-reduce state[COSTS..] again; pass = 4: decide only.  pass = 5: issue ALL
- *                         remaining step lengths (112) as one pass, to be followed by pass = 4 -- two collectives per
- *                         search instead of four for a multi-GPU caller.  The accepted
+ *                         resolved) -> all-reduce state[COSTS..] again; pass = 4: decide only.  For a multi-GPU
+ *                         caller, who pays a collective per pass: pass = 6 (issue 32) then 7 (issue the 80 that are
+ *                         left) then 4 -- three collectives per search --, or pass = 5 (all 112 at once) then 4.  The accepted
  *                         step length times 0.5 lands in state[GAMMA_PSI] (which = 0) / state[GAMMA_PRB] (which = 1).
+ *   ptycho_cg_reg_prepare (optional, multi-GPU) slot 2 <- column pass of fwd(psi, ones): the first operand of the position
+ *                         correction depends on psi and scan only, so a caller that has to wait for the gradient
+ *                         all-reduce anyway issues it in that gap; ptycho_cg_obj_finish then takes correct_positions = 2
  *   ptycho_cg_obj_finish  i > 0: position correction (:398-403; needs the zoom factors of ptycho_cg_zoom), scan[0] += shifts;
- *                         psi += gamma dpsi (:405)
+ *                         psi += gamma dpsi (:405).  correct_positions: 0 off, 1 on, 2 on with slot 2 prepared
  *   ptycho_cg_prb_grad    slot 0 <- column pass of fwd(psi, probe); slot 1 <- projected residual (:421-430);
  *                         gprb <- adj_probe (raw).                   all-reduce: gprb
  *   ptycho_cg_prb_dir     gprb <- gprb / max|psi|^2 / nscan_total * nmodes (:431); Dai-Yuan dprb (:437-448);
@@ -211,6 +214,7 @@ int ptycho_cg_obj_grad(ptycho_handle h, double* state, const void* scan, void* p
 int ptycho_cg_obj_dir(ptycho_handle h, double* state, int first, const void* scan, const void* prb, const void* data,
                       void* grad, void* grad0, void* dpsi, void* stream);
 int ptycho_cg_ls_next(ptycho_handle h, double* state, int which, int pass, const void* data, int use_ab, void* stream);
+int ptycho_cg_reg_prepare(ptycho_handle h, double* state, const void* psi, const void* scan, const void* ones_prb, void* stream);
 int ptycho_cg_obj_finish(ptycho_handle h, double* state, int correct_positions, void* psi, const void* dpsi, void* scan,
                          const void* ones_prb, const void* vt, const void* lz, int nc, int ups, double upsample_factor,
                          void* stream);

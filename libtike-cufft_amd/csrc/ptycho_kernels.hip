@@ -1184,14 +1184,15 @@ int ls_pass(ptycho_handle h, const void* data, int use_ab, double* state, hipStr
 }
 
 template <int N>
-int do_cross_dev(ptycho_handle h, const double* gamma_dev, hipStream_t st) {
+int do_cross_dev(ptycho_handle h, const double* gamma_dev, hipStream_t st, int s1_slot) {
     RowFusedArgs a{};
-    a.s1 = h->work[0]; a.s2 = h->work[1]; a.out = h->work[1]; a.ip = h->reg_ip; a.gamma_dev = gamma_dev;
+    a.s1 = h->work[s1_slot]; a.s2 = h->work[1]; a.out = h->work[1]; a.ip = h->reg_ip; a.gamma_dev = gamma_dev;
     h->slot_max_ok[1] = false;
     return do_cg_rows<N, EP_CROSS>(h, a, st);
 }
-int cross_dev(ptycho_handle h, const double* gamma_dev, hipStream_t st) {
-    PTY_DISPATCH(h->ge.ndet, (do_cross_dev<NN>(h, gamma_dev, st)));
+int cross_dev(ptycho_handle h, const double* gamma_dev, hipStream_t st, int s1_slot = 0) {
+    if (!slot_ready(h, s1_slot) || !slot_ready(h, 1)) return fail(PTYCHO_ERR_ARG, "work slot is empty");
+    PTY_DISPATCH(h->ge.ndet, (do_cross_dev<NN>(h, gamma_dev, st, s1_slot)));
 }
 
 int check_stage(ptycho_handle h, const void* state) {
@@ -1255,11 +1256,12 @@ int ptycho_cg_obj_dir(ptycho_handle h, double* state, int first, const void* sca
 int ptycho_cg_ls_next(ptycho_handle h, double* state, int which, int pass, const void* data, int use_ab, void* stream) {
     int rc = check_stage(h, state);
     if (rc) return rc;
-    if (which < 0 || which > 1 || pass < 1 || pass > 5 || !data) return fail(PTYCHO_ERR_ARG, "bad line-search stage");
+    if (which < 0 || which > 1 || pass < 1 || pass > 7 || !data) return fail(PTYCHO_ERR_ARG, "bad line-search stage");
     hipStream_t st = (hipStream_t)stream;
     // passes: <= 16 step lengths (sized from the last accepted index), then 16, 32, 64 more: 2^-106 < 1e-32 is covered.
-    // pass 5 (for callers that pay a collective per pass): everything that is left, 112 step lengths, at once.
-    const int next_groups = pass == 1 ? 1 : (pass == 2 ? 2 : (pass == 3 ? 4 : (pass == 5 ? kLsGroupsMax : 0)));
+    // For callers that pay a collective per pass: 6 then 7 (32, then the 80 that are left), or 5 (all 112 at once).
+    static const int kNext[8] = {0, 1, 2, 4, 0, kLsGroupsMax, 2, 5};
+    const int next_groups = kNext[pass];
     hipLaunchKernelGGL(k_cg_ls_decide, dim3(1), dim3(1), 0, st, state, which,
                        which == 0 ? (int)PTYCHO_ST_GAMMA_PSI : (int)PTYCHO_ST_GAMMA_PRB, next_groups);
     HIP_TRY(hipGetLastError());
@@ -1286,11 +1288,14 @@ int ptycho_cg_obj_finish(ptycho_handle h, double* state, int correct_positions, 
             HIP_TRY(hipMalloc((void**)&h->reg_shifts, npos * 2 * sizeof(double)));
         }
         // ptycho.py:399-402: tmp1 = fwd(psi, 1), tmp2 = fwd(psi + gamma dpsi, 1) = tmp1 + gamma fwd(dpsi, 1)
-        rc = ptycho_cg_fwd_cols(h, 0, psi, scan, ones_prb, stream);
-        if (rc) return rc;
+        const int s1 = correct_positions == 2 ? 2 : 0;   // 2: ptycho_cg_reg_prepare left the column pass of tmp1 in slot 2
+        if (s1 == 0) {
+            rc = ptycho_cg_fwd_cols(h, 0, psi, scan, ones_prb, stream);
+            if (rc) return rc;
+        }
         rc = ptycho_cg_fwd_cols(h, 1, dpsi, scan, ones_prb, stream);
         if (rc) return rc;
-        rc = cross_dev(h, state + PTYCHO_ST_GAMMA_PSI, st);
+        rc = cross_dev(h, state + PTYCHO_ST_GAMMA_PSI, st, s1);
         if (rc) return rc;
         rc = ptycho_cg_argmax(h, 1, h->reg_best, stream);
         if (rc) return rc;
@@ -1304,6 +1309,14 @@ int ptycho_cg_obj_finish(ptycho_handle h, double* state, int correct_positions, 
                        (const double*)(state + PTYCHO_ST_GAMMA_PSI));
     HIP_TRY(hipGetLastError());
     return PTYCHO_OK;
+}
+
+int ptycho_cg_reg_prepare(ptycho_handle h, double* state, const void* psi, const void* scan, const void* ones_prb, void* stream) {
+    int rc = check_stage(h, state);
+    if (rc) return rc;
+    if (!psi || !scan || !ones_prb) return fail(PTYCHO_ERR_ARG, "null operand");
+    if (h->ge.ptheta != 1) return fail(PTYCHO_ERR_ARG, "native position correction needs ptheta = 1");
+    return ptycho_cg_fwd_cols(h, 2, psi, scan, ones_prb, stream);
 }
 
 int ptycho_cg_prb_grad(ptycho_handle h, double* state, const void* psi, const void* scan, const void* prb,

@@ -22,6 +22,7 @@ SYMBOLS = ("ptycho_create", "ptycho_free", "ptycho_destroy", "ptycho_get",
            "ptycho_cg_cross", "ptycho_cg_argmax", "ptycho_cg_zoom",
            "ptycho_cg_fwd_cols_modes", "ptycho_cg_linesearch_chunk",
            "ptycho_cg_obj_begin", "ptycho_cg_obj_grad", "ptycho_cg_obj_dir", "ptycho_cg_ls_next",
+           "ptycho_cg_reg_prepare",
            "ptycho_cg_obj_finish", "ptycho_cg_prb_grad", "ptycho_cg_prb_dir", "ptycho_cg_prb_finish",
            "ptycho_last_error", "ptycho_version")
 
@@ -69,6 +70,7 @@ cg_obj_begin = _sig("ptycho_cg_obj_begin", _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp
 cg_obj_grad = _sig("ptycho_cg_obj_grad", _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp)
 cg_obj_dir = _sig("ptycho_cg_obj_dir", _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp)
 cg_ls_next = _sig("ptycho_cg_ls_next", _i, _vp, _vp, _i, _i, _vp, _i, _vp)
+cg_reg_prepare = _sig("ptycho_cg_reg_prepare", _i, _vp, _vp, _vp, _vp, _vp, _vp)
 cg_obj_finish = _sig("ptycho_cg_obj_finish", _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _d, _vp)
 cg_prb_grad = _sig("ptycho_cg_prb_grad", _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp)
 cg_prb_dir = _sig("ptycho_cg_prb_dir", _i, _vp, _vp, _i, _d, _d, _vp, _vp, _vp, _vp, _vp, _vp, _vp)

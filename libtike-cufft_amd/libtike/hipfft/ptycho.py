@@ -571,7 +571,7 @@ class CGPtychoSolver(PtychoHIP):
         self.native = True     # single-mode loop sequenced by the native stage calls (no host round trips)
         self._nscan_all = None
         self.reproducible = True  # fused CG loops use the deterministic adjoints (same trajectory every run)
-        self.ls_two_pass = None  # native line search in two passes (<= 16, then 112 step lengths); None: with a group only
+        self.ls_two_pass = None  # native line search with few collectives (<= 16, 32, 80 step lengths); None: with a group only
 
     # -- distributed glue ----------------------------------------------------
     def _allreduce(self, t):
@@ -713,12 +713,15 @@ class CGPtychoSolver(PtychoHIP):
             gprb, gprb0, dprb = (torch.zeros_like(probe[:, 0]) for _ in range(3))
         nscan_total = float(self._nscan_total())
         dist_on = self.group is not None
-        two_pass = dist_on if self.ls_two_pass is None else bool(self.ls_two_pass)
+        two_pass = dist_on if self.ls_two_pass is None else self.ls_two_pass
 
         def line_search(which, use_ab, S):
             # one GPU: 16 + 32 + 64 more step lengths in passes that return at once when resolved; with a
-            # process group every pass costs a collective, so the second one prices all that is left
-            for p in ((5, 4) if two_pass else (1, 2, 3, 4)):
+            # process group every pass costs a collective: 32, then all 80 that are left (a second pass of all 112
+            # would save one more collective, but a search that ends at index 30-50 -- a quarter of the bench
+            # problem's iterations -- would then price 112 step lengths instead of 32: +2 ms per iteration at 4096
+            # positions; ls_two_pass = "all" selects it)
+            for p in ((5, 4) if two_pass == "all" else (6, 7, 4) if two_pass else (1, 2, 3, 4)):
                 if dist_on:
                     self._allreduce(costs)
                 nat.check(nat.cg_ls_next(h, sp, which, p, _ptr(data), use_ab, S))
@@ -732,7 +735,14 @@ class CGPtychoSolver(PtychoHIP):
                 self._allreduce(st[nat.ST_A:nat.ST_A + 2])
             nat.check(nat.cg_obj_grad(h, sp, _ptr(scan), _ptr(probe), _ptr(data), _ptr(grad), S))
             if dist_on:
-                self._allreduce(grad)
+                # the gradient all-reduce runs on the communicator's stream; the first operand of the position
+                # correction (column pass of fwd(psi, 1): depends on psi and scan only) is computed under it
+                import torch.distributed as dist
+                work = dist.all_reduce(torch.view_as_real(grad), group=self.group, async_op=True)
+                if correct:
+                    nat.check(nat.cg_reg_prepare(h, sp, _ptr(psi), _ptr(scan), _ptr(ones), S))
+                    correct = 2
+                work.wait()
             nat.check(nat.cg_obj_dir(h, sp, first, _ptr(scan), _ptr(probe), _ptr(data), _ptr(grad),
                                      _ptr(grad0), _ptr(dpsi), S))
             line_search(0, 1, S)

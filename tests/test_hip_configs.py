@@ -164,25 +164,29 @@ def test_cg_full_size_properties(pt):
         got = slv.run(data, psi_true.clone(), scan.clone(), probe.clone(), piter=1)
         assert float(torch.abs(got["psi"] - psi_true).max()) < 1e-4
 
-        # (4) the two line-search schedules of the native loop (passes of <=16, 16, 32, 64 step lengths on one GPU;
-        # <=16, 112 with a process group, one collective per pass) accept the same steps.  From the flat start the
-        # first searches of this problem go far beyond the first 16 step lengths, where the schedules differ.
+        # (4) the line-search schedules of the native loop (passes of <=16, 16, 32, 64 step lengths on one GPU;
+        # <=16, 32, 80 with a process group, one collective per pass; <=16, 112 on request) accept the same steps.
+        # From the flat start the first searches of this problem go far beyond the first 16 step lengths, where the
+        # schedules differ.
         smooth = torch.as_tensor(np.ascontiguousarray(p["probe"][:, None]), device="cuda")   # bench.py's probe
         data = (torch.abs(slv.fwd(psi_true, scan, smooth[:, 0])) ** 2).contiguous()
         # deep searches decide between float32 costs that differ in the last digits, so the float-atomic adjoint's
         # run-to-run rounding noise can move an accepted index; the fixed-point adjoints take that out
         slv.set_deterministic(True)
         res = []
-        for two in (False, True):
+        for two in (False, True, "all"):
             slv.ls_two_pass = two
             slv.history = []
             r = slv.run(data, torch.ones_like(psi_true), scan.clone(), smooth.clone(), piter=4, recover_prb=True)
             res.append((r["psi"].clone(), list(slv.history)))
             del r
-        (pa, ha), (pb, hb) = res
+        (pa, ha), (pb, hb), (pc, hc) = res
         assert min(h[1] for h in ha) < 2.0 ** -18, ha
         check_history(ha, hb)
+        check_history(ha, hc)
         assert float(torch.abs(pa - pb).max() / torch.abs(pb).max()) < 2e-4
+        assert float(torch.abs(pa - pc).max() / torch.abs(pc).max()) < 2e-4
+        slv.ls_two_pass = None
 
 
 def _dot(a, b, step=1024):
