@@ -121,8 +121,13 @@ __device__ __forceinline__ int ls_first_ncand(const double hint) {
 __global__ void k_cg_ls_prepare(double* __restrict__ st, const int which) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     st[PTYCHO_ST_LS_GAMMA0] = 1.0;
-    st[PTYCHO_ST_LS_NCAND] = (double)ls_first_ncand(st[PTYCHO_ST_HINT + which]);
-    st[PTYCHO_ST_LS_NGROUPS] = 1.0;
+    // the last search of this kind ended beyond the first 16 step lengths: the next one almost always does too, so
+    // the first pass prices whole groups of 16 up to that index (same groups, same sums as the later passes would form)
+    const int want = (int)st[PTYCHO_ST_HINT + which] + 2;
+    int ng = want > kMaxCand ? (want + kMaxCand - 1) / kMaxCand : 1;
+    ng = ng > 4 ? 4 : ng;
+    st[PTYCHO_ST_LS_NCAND] = ng > 1 ? (double)kMaxCand : (double)ls_first_ncand(st[PTYCHO_ST_HINT + which]);
+    st[PTYCHO_ST_LS_NGROUPS] = (double)ng;
     st[PTYCHO_ST_LS_TRIED] = 0.0;
     st[PTYCHO_ST_LS_RESOLVED] = 0.0;
     for (int i = 0; i < kLsGroupsMax * (kMaxCand + 1); ++i) st[PTYCHO_ST_COSTS + i] = 0.0;
