@@ -684,8 +684,11 @@ __global__ __launch_bounds__(256) void k_rank_positions(const float* __restrict_
 // Column pass of the coarse cross-correlation with a fused arg-max (ptycho.py:204-207):
 // inverse DFT over y of the slot's tiles, |.|, and per position the first maximum as a packed
 // 64-bit key (value bits << 32 | ~flat index) merged with atomicMax.
+// N = 256: the step-1 twiddles are re-read per tile from an LDS copy of the table, which brings the kernel under 128
+// registers -- four waves per SIMD without spills (forcing four waves with the twiddles in registers spilled 30
+// registers and ran 0.49 -> 0.75 ms).
 template <int N>
-__global__ __launch_bounds__(ColCfg<N>::NT) void k_cols_argmax(const c32* __restrict__ tiles, const c32* __restrict__ table,
+__global__ __launch_bounds__(ColCfg<N>::NT, (N == 256 ? 4 : 1)) void k_cols_argmax(const c32* __restrict__ tiles, const c32* __restrict__ table,
                                                                unsigned long long* __restrict__ best, const int npos,
                                                                const int ngroups) {
     using P = Plan<N>;
@@ -693,16 +696,25 @@ __global__ __launch_bounds__(ColCfg<N>::NT) void k_cols_argmax(const c32* __rest
     constexpr int E = P::E, T = P::T, C = ColCfg<N>::C, NT = ColCfg<N>::NT;
     constexpr int LAST = P::NSTEP - 1;
     constexpr int NW = (NT + 63) / 64;
+    constexpr bool TWLDS = N == 256;
     __shared__ c32 lds[N * C];
     __shared__ unsigned long long red[NW];
+    __shared__ c32 wtab[TWLDS ? N : 1];
     const int tid = threadIdx.x;
     const int c = tid % C, j0 = tid / C;
     constexpr int nstrips = N / C;
     const int strip = blockIdx.x % nstrips, group = blockIdx.x / nstrips;
     const int x = strip * C + c;
     F fft;
-    fft.init(j0, table);
+    int jz = j0;
+    if constexpr (TWLDS) {
+        for (int o = tid; o < N; o += NT) wtab[o] = table[o];
+        __syncthreads();
+    } else {
+        fft.init(j0, table);
+    }
     for (int p = group; p < npos; p += ngroups) {
+        if constexpr (TWLDS) asm volatile("" : "+v"(jz));
         const c32* tile = tiles + (size_t)p * N * N;
         c32 v[E];
         fft.template load<0>(v, j0, [&](int i) { return tile[(size_t)i * N + x]; });
@@ -718,6 +730,7 @@ __global__ __launch_bounds__(ColCfg<N>::NT) void k_cols_argmax(const c32* __rest
                 __syncthreads();
                 fft.template load<2>(v, j0, [&](int i) { return lds[i * C + c]; });
             }
+            if constexpr (TWLDS) fft.template init_step<LAST>(jz, wtab);
             fft.template compute<LAST>(v);
         }
         c32 nat[E];
