@@ -235,6 +235,34 @@ def test_cg_at_a_cropped_detector_size(pt):
     assert np.abs(got["psi"] - want["psi"]).max() < 2e-4 * np.abs(want["psi"]).max()
 
 
+def test_cg_runs_are_bitwise_reproducible(pt):
+    """The fused loops use the deterministic adjoints (``solver.reproducible``, default on): two runs of the same
+    problem give the same bits -- object, probe, positions and logged costs; with the reference's float ``atomicAdd``
+    (kernels.cu:73-80) they do not.  One mode (native stage loop) and three modes (compact slot layout)."""
+    ndet = 64
+    p = syn.make_problem(6, 6, 8, ndet, ndet, seed=5)
+    rng = np.random.default_rng(6)
+    for M in (1, 3):
+        probe = np.stack([p["probe"] * np.exp(2j * np.pi * rng.random((ndet, ndet))) / (k + 1) for k in range(M)], axis=1).astype(np.complex64)
+        ora = cg.OracleSolver(p["nscan"], ndet, ndet, 1, p["nz"], p["n"])
+        data = sum(np.abs(ora.fwd(p["psi"], p["scan"], probe[:, k])) ** 2 for k in range(M)).astype(np.float32)
+        runs = []
+        for rep in range(2):
+            with pt.CGPtychoSolver(p["nscan"], ndet, ndet, 1, p["nz"], p["n"]) as slv:
+                slv.verbose, slv.log_every = False, 1
+                assert slv.reproducible
+                import torch
+                scan = torch.as_tensor(p["scan"].copy(), device="cuda")
+                got = slv.run(torch.as_tensor(data, device="cuda"), torch.ones((1, p["nz"], p["n"]), dtype=torch.complex64, device="cuda"),
+                              scan, torch.as_tensor(probe.copy(), device="cuda"), piter=5, recover_prb=True)
+                runs.append((got["psi"].cpu().numpy(), got["probe"].cpu().numpy(), scan.cpu().numpy(), list(slv.history)))
+        a, b = runs
+        np.testing.assert_array_equal(a[0], b[0])
+        np.testing.assert_array_equal(a[1], b[1])
+        np.testing.assert_array_equal(a[2], b[2])
+        assert a[3] == b[3]
+
+
 def test_fused_registration_right_on_its_first_launch():
     """DESIGN.md (round 1) recorded an occupancy-capped variant of the registration row pass that was wrong on its
     first launch in a process and right afterwards.  That variant is gone; this pins the shipped path: in a FRESH
