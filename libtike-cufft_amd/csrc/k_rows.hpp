@@ -225,7 +225,7 @@ __global__ __launch_bounds__(256, (fused_min_waves<N, EP>())) void k_rows_fused(
     __shared__ c32 stash[(EP == EP_CROSS || EP == EP_LINESEARCH_M) ? E * 256 : 1];
     // three-step plans at two waves per SIMD: the 2 x 16 inter-step twiddles do not stay in registers across the
     // batch loop (64 VGPRs); each step re-reads its set from an LDS copy of the table (Fft::init_step)
-    constexpr bool TWLDS = (P::NSTEP > 2 && fused_min_waves<N, EP>() > 1) || (N == 256 && (EP == EP_LINESEARCH || EP == EP_LINESEARCH_M));
+    constexpr bool TWLDS = (P::NSTEP > 2 && fused_min_waves<N, EP>() > 1) || (N <= 256 && P::NSTEP > 1 && (EP == EP_LINESEARCH || EP == EP_LINESEARCH_M));
     __shared__ c32 wtab[TWLDS ? N : 1];
 
     const int tid = threadIdx.x;
