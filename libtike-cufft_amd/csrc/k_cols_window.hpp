@@ -218,7 +218,36 @@ __global__ __launch_bounds__(ColCfg<N>::NT) void k_cols_adjwin(const ColArgs a, 
             c32 up0 = tp[1], up1 = tp[0];                         // T[y-1][cc], T[y-1][cc-1]
             int slot = (q.sy + y0) % H;
             const int colw = Xa - X0 + cc;
-            for (int yy = y0; yy < y1; ++yy) {
+            int yy = y0;
+            // U rows per trip: the tile taps and the window values of all U rows are requested before the first is used
+            // (the one-row loop waits for an LDS round trip per row: the combine is a latency chain, not bandwidth)
+            auto trips = [&](auto uc) {
+                constexpr int U = decltype(uc)::value;
+                for (; yy + U <= y1; yy += U) {
+                    c32 t0[U], t1[U], wv[U];
+                    c32* wp[U];
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const c32* tq = tp + (u + 1) * CP;
+                        int su = slot + u;
+                        su = su >= H ? su - H : su;
+                        wp[u] = win + su * WC + colw;
+                        t0[u] = tq[1]; t1[u] = tq[0];
+                    }
+#pragma unroll
+                    for (int u = 0; u < U; ++u) wv[u] = *wp[u];
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        *wp[u] = wv[u] + (t0[u] * w00 + t1[u] * w01 + up0 * w10 + up1 * w11);
+                        up0 = t0[u]; up1 = t1[u];
+                    }
+                    tp += U * CP;
+                    slot += U;
+                    slot = slot >= H ? slot - H : slot;
+                }
+            };
+            trips(std::integral_constant<int, 3>{});
+            for (; yy < y1; ++yy) {
                 tp += CP;
                 const c32 t00 = tp[1], t01 = tp[0];
                 win[slot * WC + colw] += t00 * w00 + t01 * w01 + up0 * w10 + up1 * w11;
