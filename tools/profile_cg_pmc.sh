@@ -6,7 +6,7 @@ TAG=${1:-r01}
 OUT=gpurun_out/profcgpmc_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
-BENCH="python3 bench.py --steps 3 --warmup 1 --no-cpu --cg-iters 8"
+BENCH="python3 bench.py --steps 3 --warmup 1 --no-cpu --no-cfg3 --cg-iters 8"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- $BENCH > /dev/null 2> $OUT/pmc_fetch.err
 echo "fetch rc=$?"
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- $BENCH > /dev/null 2> $OUT/pmc_write.err
