@@ -14,6 +14,7 @@
 //   k_cg_add_shifts    scan[0] += shifts                                           (ptycho.py:403)
 #pragma once
 
+static_assert(kLsGroupsRows == 7, "k_rows.hpp sizes its line-search accumulators for 7 groups");
 constexpr int kLsGroupsMax = 7;   // a line-search pass prices up to 7 groups of 16 step lengths
 
 __global__ void k_cg_scale_probe(c32* __restrict__ prb, const long long n, const double* __restrict__ st) {

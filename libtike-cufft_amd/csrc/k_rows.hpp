@@ -166,6 +166,7 @@ __device__ __forceinline__ float frcp(float x) { return __builtin_amdgcn_rcpf(x)
 enum RowEp { EP_STATS = 1, EP_PROJECT = 2, EP_LINESEARCH = 3, EP_CROSS = 6, EP_LINESEARCH_M = 7, EP_STATS_M = 8 };
 constexpr int kMaxModes = 8;   // EP_LINESEARCH_M: slot pairs (2k, 2k+1), k < nmodes
 constexpr int kMaxCand = 16;
+constexpr int kLsGroupsRows = 7;   // = kLsGroupsMax (k_cg_small.hpp): groups of 16 step lengths one pass may price
 
 struct RowFusedArgs {
     const c32* s1;
@@ -223,6 +224,10 @@ __global__ __launch_bounds__(256, (fused_min_waves<N, EP>())) void k_rows_fused(
     __shared__ c32 lds[P::NSTEP > 1 ? B * L::FS : 1];
     __shared__ double red[4 * NACC];
     __shared__ c32 stash[(EP == EP_CROSS || EP == EP_LINESEARCH_M) ? E * 256 : 1];
+    // single-mode line search with several groups of 16 step lengths in ONE sweep: per batch every wave folds its
+    // partial costs of a group into these float64 accumulators (one row per wave) instead of keeping 17 registers per
+    // group alive across the batch loop; the inputs are read and transformed once for all groups
+    __shared__ double gacc[EP == EP_LINESEARCH ? 4 * kLsGroupsRows * (kMaxCand + 1) : 1];
     // three-step plans at two waves per SIMD: the 2 x 16 inter-step twiddles do not stay in registers across the
     // batch loop (64 VGPRs); each step re-reads its set from an LDS copy of the table (Fft::init_step)
     constexpr bool TWLDS = (P::NSTEP > 2 && fused_min_waves<N, EP>() > 1) || (N <= 256 && P::NSTEP > 1 && (EP == EP_LINESEARCH || EP == EP_LINESEARCH_M));
@@ -290,7 +295,13 @@ __global__ __launch_bounds__(256, (fused_min_waves<N, EP>())) void k_rows_fused(
     };
 
     const long long nb = (a.nrows + B - 1) / B;
-    for (int grp = 0; grp < ngroups; ++grp) {   // line search: groups of 16 step lengths, one sweep each (else one pass)
+    const bool multi = EP == EP_LINESEARCH && ngroups > 1;   // uniform; full groups (ncand = 16) by construction
+    if (EP == EP_LINESEARCH && multi) {
+        for (int o = tid; o < 4 * kLsGroupsRows * (kMaxCand + 1); o += 256) gacc[o] = 0.0;
+        __syncthreads();
+    }
+    const int nsweeps = multi ? 1 : ngroups;
+    for (int grp = 0; grp < nsweeps; ++grp) {   // multi-mode line search: one sweep per group of 16 step lengths (else one pass)
     const float gam_first = gamma0 * exp2f(-16.0f * (float)grp);
     if (grp > 0) {
 #pragma unroll
@@ -492,6 +503,13 @@ __global__ __launch_bounds__(256, (fused_min_waves<N, EP>())) void k_rows_fused(
             // two detector pixels per step in packed float32 (v_pk_fma_f32 / v_pk_add_f32), four
             // step lengths per uniform branch: per trial and pixel 2 FMA for p1 + y^2 p2 + y p3,
             // one v_sqrt_f32, one subtract, one FMA into the cost
+            const int ginner = multi ? ngroups : 1;
+            for (int gi = 0; gi < ginner; ++gi) {
+            const float gfirst = multi ? gamma0 * exp2f(-16.0f * (float)gi) : gam_first;
+            if (multi) {
+#pragma unroll
+                for (int i = 0; i < NACC; ++i) acc2[i] = c32{0.0f, 0.0f};
+            }
 #pragma unroll
             for (int m = 0; m < E; m += 2) {
                 const c32 ta = g1[m] * s, tb = g1[m + 1] * s;
@@ -501,7 +519,7 @@ __global__ __launch_bounds__(256, (fused_min_waves<N, EP>())) void k_rows_fused(
                 const c32 sd = c32{fsqrt(d[m]), fsqrt(d[m + 1])};
                 c32 df = c32{fsqrt(fabsf(p1.x)), fsqrt(fabsf(p1.y))} - sd;
                 acc2[kMaxCand] += df * df;
-                float gam = gam_first;
+                float gam = gfirst;
 #pragma unroll
                 for (int j0c = 0; j0c < kMaxCand; j0c += 4) {
                     if (j0c < ncand) {
@@ -515,7 +533,43 @@ __global__ __launch_bounds__(256, (fused_min_waves<N, EP>())) void k_rows_fused(
                     }
                 }
             }
+            if (multi) {
+                // wave reduction of the 16 + 1 partial costs: halve the values per lane at every exchange (15 + 2
+                // shuffles for the 16, 6 for f(p1)); lane l < 16 ends up with the wave total of value brev4(l)
+                const int lane = tid & 63, wave = tid >> 6;
+                float r[kMaxCand];
+#pragma unroll
+                for (int i = 0; i < kMaxCand; ++i) r[i] = acc2[i].x + acc2[i].y;
+                float x16 = acc2[kMaxCand].x + acc2[kMaxCand].y;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { const bool up = lane & 1; const float keep = up ? r[i + 8] : r[i], send = up ? r[i] : r[i + 8]; r[i] = keep + __shfl_xor(send, 1, 64); }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { const bool up = lane & 2; const float keep = up ? r[i + 4] : r[i], send = up ? r[i] : r[i + 4]; r[i] = keep + __shfl_xor(send, 2, 64); }
+#pragma unroll
+                for (int i = 0; i < 2; ++i) { const bool up = lane & 4; const float keep = up ? r[i + 2] : r[i], send = up ? r[i] : r[i + 2]; r[i] = keep + __shfl_xor(send, 4, 64); }
+                { const bool up = lane & 8; const float keep = up ? r[1] : r[0], send = up ? r[0] : r[1]; r[0] = keep + __shfl_xor(send, 8, 64); }
+                float x = r[0];
+                x += __shfl_xor(x, 16, 64);
+                x += __shfl_xor(x, 32, 64);
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) x16 += __shfl_xor(x16, off, 64);
+                double* ga = gacc + (wave * kLsGroupsRows + gi) * (kMaxCand + 1);
+                if (lane < 16) ga[((lane & 1) << 3) | ((lane & 2) << 1) | ((lane & 4) >> 1) | ((lane & 8) >> 3)] += (double)x;
+                if (lane == 0) ga[kMaxCand] += (double)x16;
+            }
+            }   // gi
         }
+    }
+    if (EP == EP_LINESEARCH && multi) {   // fold the four waves' accumulators into the state (f(p1) of a group behind its 16 costs)
+        __syncthreads();
+        for (int o = tid; o < ngroups * (kMaxCand + 1); o += 256) {
+            const int gi = o / (kMaxCand + 1), i = o % (kMaxCand + 1);
+            double x = 0.0;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) x += gacc[(w * kLsGroupsRows + gi) * (kMaxCand + 1) + i];
+            atomicAdd(sums + gi * (kMaxCand + 1) + i, x);
+        }
+        return;
     }
     if (LS) {
 #pragma unroll

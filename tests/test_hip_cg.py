@@ -235,6 +235,57 @@ def test_cg_at_a_cropped_detector_size(pt):
     assert np.abs(got["psi"] - want["psi"]).max() < 2e-4 * np.abs(want["psi"]).max()
 
 
+def test_line_search_decision_kernel_replays_the_reference_rule(pt):
+    """``k_cg_ls_decide`` (C ABI ``ptycho_cg_ls_next(pass = 4)``: decide only) on hand-made cost tables, against a
+    transcription of ``line_search_sqr`` (ptycho.py:253-281): first step length whose float32 cost is not above
+    f(p1) wins, 0.5 * step lands in the gamma word, the accepted index becomes the hint; below 1e-32 the search fails
+    (gamma 0, failure counter + 1).  Several groups of 16 per pass, continuation over passes (gamma0 / tried)."""
+    import torch
+    from libtike.hipfft import _native as nat
+    from libtike.hipfft.ptycho import _ptr, _stream
+    LS_GAMMA0, LS_NCAND, LS_NGROUPS, LS_TRIED, LS_RESOLVED = 14, 15, 16, 17, 18     # enum PTYCHO_ST_* (ptycho_hip.h)
+    rng = np.random.default_rng(12)
+    with pt.CGPtychoSolver(4, 16, 16, 1, 48, 48) as slv:
+        dummy = torch.zeros(4, device="cuda")
+        for case in range(40):
+            ngroups = int(rng.integers(1, 8))
+            ncand = 16 if ngroups > 1 else int(rng.choice([4, 8, 12, 16]))
+            tried0 = int(rng.choice([0, 4, 16, 48]))
+            gamma0 = 0.5 ** tried0
+            fp1 = float(rng.uniform(1.0, 2.0)) * 1e6
+            table = np.zeros((7, 17))
+            accept_at = int(rng.integers(0, ngroups * ncand + 6))      # beyond the pass: unresolved
+            for g in range(ngroups):
+                for j in range(ncand):
+                    k = g * ncand + j
+                    table[g, j] = fp1 * (1.0 + 1e-3) if k < accept_at else fp1 * (1.0 - 1e-3 * rng.random())
+                    if k == accept_at and case % 3 == 0:
+                        table[g, j] = np.float64(np.float32(fp1)) * (1.0 + 1e-9)   # equal in float32: "not above" accepts
+                table[g, ncand] = fp1
+            st = torch.zeros(nat.ST_WORDS, dtype=torch.float64)
+            st[nat.ST_HINT:nat.ST_HINT + 2] = 14.0
+            st[LS_GAMMA0], st[LS_NCAND], st[LS_NGROUPS], st[LS_TRIED] = gamma0, ncand, ngroups, tried0
+            st[nat.ST_COSTS:nat.ST_COSTS + 7 * 17] = torch.as_tensor(table.ravel())
+            st = st.cuda()
+            nat.check(nat.cg_ls_next(slv._h, _ptr(st), 0, 4, _ptr(dummy), 0, _stream()))
+            got = st.cpu().numpy()
+            # transcription of the rule over this pass's step lengths
+            step, want_gamma, want_hint, failed, resolved = gamma0, None, 14.0, 0, False
+            for k in range(ngroups * ncand):
+                g, j = divmod(k, ncand)
+                if not (np.float32(table[g, j]) > np.float32(table[g, ncand])):
+                    want_gamma, want_hint, resolved = 0.5 * step, float(tried0 + k), True
+                    break
+                if step < 1e-32:
+                    want_gamma, failed, resolved = 0.0, 1, True
+                    break
+                step *= 0.5
+            if not resolved:            # pass 4 is the last one: the kernel's fail-safe closes the search
+                want_gamma, failed = 0.0, 1
+            assert got[nat.ST_GAMMA_PSI] == want_gamma, (case, got[nat.ST_GAMMA_PSI], want_gamma)
+            assert got[nat.ST_HINT] == want_hint and got[nat.ST_LS_FAILED] == failed and got[LS_RESOLVED] == 1.0, case
+
+
 def test_cg_runs_are_bitwise_reproducible(pt):
     """The fused loops use the deterministic adjoints (``solver.reproducible``, default on): two runs of the same
     problem give the same bits -- object, probe, positions and logged costs; with the reference's float ``atomicAdd``
