@@ -764,13 +764,26 @@ __global__ __launch_bounds__(ColCfg<N>::NT, (N == 256 ? 4 : 1)) void k_cols_argm
         }
         c32 nat[E];
         F::to_natural(v, nat);
+        // key = (bits of |v| << 32) | ~index, maximised: largest |v|, first index among equals -- |v| = sqrtf(|v|^2)
+        // correctly rounded as np.abs gives it.  Only elements whose |v|^2 lies within 2^-21 of the thread's largest
+        // can reach or tie its square root (distinct squares two ulps apart already round apart), so the 15-instruction
+        // sqrtf runs for those only -- one per thread but for near ties.
+        float m2[E], m2max = 0.0f;
+#pragma unroll
+        for (int m = 0; m < E; ++m) {
+            m2[m] = nat[m].x * nat[m].x + nat[m].y * nat[m].y;
+            m2max = fmaxf(m2max, m2[m]);
+        }
+        const float near = m2max * (1.0f - 4.76837158e-7f);
         unsigned long long key = 0ull;
 #pragma unroll
         for (int m = 0; m < E; ++m) {
-            const float mag = sqrtf(nat[m].x * nat[m].x + nat[m].y * nat[m].y);
-            const unsigned idx = (unsigned)((j0 + m * T) * N + x);
-            const unsigned long long k2 = ((unsigned long long)__float_as_uint(mag) << 32) | (unsigned long long)(0xffffffffu - idx);
-            key = k2 > key ? k2 : key;
+            if (m2[m] >= near) {
+                const float mag = sqrtf(m2[m]);
+                const unsigned idx = (unsigned)((j0 + m * T) * N + x);
+                const unsigned long long k2 = ((unsigned long long)__float_as_uint(mag) << 32) | (unsigned long long)(0xffffffffu - idx);
+                key = k2 > key ? k2 : key;
+            }
         }
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) {
