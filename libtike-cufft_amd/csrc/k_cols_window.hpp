@@ -49,6 +49,7 @@ __global__ __launch_bounds__(ColCfg<N>::NT) void k_cols_adjwin(const ColArgs a, 
     const bool col_ok = ix >= 0 && ix < ge.nprb;
     const float cinv = 1.0f / (float)N;
     const c32 zero = c32{0.0f, 0.0f};
+    const float det_sc = a.det_acc ? det_scale_of(a.det) : 0.0f;   // deterministic option: float -> fixed point
     auto at = [&](int i) { return (i + 1) * CP + c + 1; };
 
     F fft;
@@ -74,7 +75,7 @@ __global__ __launch_bounds__(ColCfg<N>::NT) void k_cols_adjwin(const ColArgs a, 
             if ((v.x != 0.0f || v.y != 0.0f) && Y < ge.nz && X >= 0 && X < ge.n) {
                 const size_t e = ((size_t)t_w * ge.nz + Y) * ge.n + X;
                 if (a.det_acc) {
-                    const float sc = *a.det_scale;
+                    const float sc = det_sc;
                     atomicAdd(reinterpret_cast<unsigned long long*>(a.det_acc + 2 * e), (unsigned long long)__float2ll_rn(v.x * sc));
                     atomicAdd(reinterpret_cast<unsigned long long*>(a.det_acc + 2 * e + 1), (unsigned long long)__float2ll_rn(v.y * sc));
                 } else {
@@ -112,6 +113,7 @@ __global__ __launch_bounds__(ColCfg<N>::NT) void k_cols_adjwin(const ColArgs a, 
     };
 
     __syncthreads();
+    STAMP_DECL
     St st = decode(kb);
     c32 v[E];
     if (st.have && st.q.valid) {
@@ -144,6 +146,9 @@ __global__ __launch_bounds__(ColCfg<N>::NT) void k_cols_adjwin(const ColArgs a, 
             cur_t = st.t;
         }
         // ---- inverse DFT over y of this strip (tile already in v) ----------------------
+        STAMP(0)          // loop head, decode, probe strip
+        STAMP_DRAIN();
+        STAMP(1)          // wait for the tile loads
         if (SPLIT) {
             fft.template compute<LAST>(v);   // twiddle + radix 16: the step k_rows_split left
         } else {
@@ -173,10 +178,13 @@ __global__ __launch_bounds__(ColCfg<N>::NT) void k_cols_adjwin(const ColArgs a, 
             }
             // split kernel: no exchange went through the tile, so the "previous combine is done"
             // barrier sits here, after this position's transform, instead of at the end of the loop
+            STAMP(2)      // transform + probe product
             if (SPLIT) __syncthreads();
+            STAMP(3)      // barrier: previous combine done
 #pragma unroll
             for (int m = 0; m < E; ++m) lds[at(j0 + m * T)] = nat[m];
         }
+        STAMP(8)          // T store
         // prefetch the next tile while the combine runs
         if (nx.have && nx.q.valid) {
             const c32* tile_in = tile_of(nx, k + 1);
@@ -185,6 +193,7 @@ __global__ __launch_bounds__(ColCfg<N>::NT) void k_cols_adjwin(const ColArgs a, 
             else
                 fft.template load<(SPLIT ? 1 : 0)>(v, j0, [&](int i) { return tile_in[(size_t)i * N + x]; });
         }
+        STAMP(9)          // prefetch issue
         // ---- window bookkeeping (all quantities are workgroup-uniform) -------------------
         const int Xa = q.sx + x0 - ge.pad;   // object column of strip column cc = 0
         const bool fitsw = (st.t == t_w) && Xa >= X0 && Xa + C < X0 + WC && q.sy >= Ybase;
@@ -201,7 +210,9 @@ __global__ __launch_bounds__(ColCfg<N>::NT) void k_cols_adjwin(const ColArgs a, 
             if (Ytop < Ybase) Ytop = Ybase;
         }
         if (Ytop < q.sy + ge.nprb + 1) Ytop = q.sy + ge.nprb + 1;
+        STAMP(4)          // T store, prefetch issue, window bookkeeping, flush
         __syncthreads();   // T tile complete (and, after a re-anchor, the window is clean)
+        STAMP(5)          // barrier: T tile complete
         // ---- 4-tap bilinear combine (kernels.cu:73-80) into the window -------------------
         for (int item = tid; item < NITEM; item += NT) {
             const int cc = item % (C + 1), rg = item / (C + 1);
@@ -255,11 +266,14 @@ __global__ __launch_bounds__(ColCfg<N>::NT) void k_cols_adjwin(const ColArgs a, 
                 slot = slot + 1 == H ? 0 : slot + 1;
             }
         }
+        STAMP(6)          // combine
         if (!SPLIT) __syncthreads();   // combine done: the tile may be overwritten by the next position
         st = nx;
     }
     __syncthreads();
     flush(Ybase, Ytop);
+    STAMP(7)
+    STAMP_FLUSH(a.stamps ? a.stamps + 12 : a.stamps)
 }
 
 // ---------------------------------------------------------------------------
@@ -304,6 +318,7 @@ __global__ __launch_bounds__(ColCfg<N>::NT) void k_cols_gatherwin(const ColArgs 
     const bool col_ok = ix >= 0 && ix < ge.nprb;
     const float cinv = 1.0f / (float)N;
     const c32 zero = c32{0.0f, 0.0f};
+    const float det_sc = (MODE == M_ADJ_PRB && a.det_acc) ? det_scale_of(a.det) : 0.0f;   // deterministic option
 
     // NM > 1: the inter-step twiddles are re-read from an LDS copy of the table before each step (init_step) instead
     // of living in up to 64 VGPRs next to the shared patch values and the probe strip in flight
@@ -342,7 +357,7 @@ __global__ __launch_bounds__(ColCfg<N>::NT) void k_cols_gatherwin(const ColArgs 
                 const size_t e = ((size_t)t * ge.nprb + iy) * ge.nprb + ix;
                 const c32 sacc = pr[m] * cinv;
                 if (a.det_acc) {
-                    const float sc = *a.det_scale;
+                    const float sc = det_sc;
                     atomicAdd(reinterpret_cast<unsigned long long*>(a.det_acc + 2 * e), (unsigned long long)__float2ll_rn(sacc.x * sc));
                     atomicAdd(reinterpret_cast<unsigned long long*>(a.det_acc + 2 * e + 1), (unsigned long long)__float2ll_rn(sacc.y * sc));
                 } else {
@@ -368,11 +383,29 @@ __global__ __launch_bounds__(ColCfg<N>::NT) void k_cols_gatherwin(const ColArgs 
     //                  is loaded in place by prepare_issue.
     c32 pre_val = zero;
     int pre_slot = -1;
-    auto prepare_issue = [&](int k, int kend) -> St {
+    bool pre_inb = false;
+    // deferred re-anchor (prepare_issue called with defer = true BEFORE the barrier that ends the reads of the
+    // current window: it may start a register load, but must not write the window)
+    int bulk_cnt = 0, bulk_y0 = 0;
+    const c32* bulk_ft = nullptr;
+    auto bulk_fill = [&](const c32* ft, int y0, int cnt) {
+        for (int o = tid; o < cnt; o += NT) {
+            const int Y = y0 + o / WC, col = o % WC;
+            const int X = X0 + col;
+            const bool inb = Y < ge.nz && X >= 0 && X < ge.n;
+            const c32 val = ft[inb ? ((size_t)Y * ge.n + X) : 0];
+            const int ws = (Y % H) * WC + col;
+            win[ws] = inb ? val : zero;
+            if (ws < WC) win[H * WC + ws] = inb ? val : zero;   // mirror of row 0
+        }
+    };
+    auto prepare_issue = [&](int k, int kend, auto defer_c) -> St {
+        constexpr bool defer = decltype(defer_c)::value;
         St st;
         st.have = k < kend;
         st.p = 0; st.t = 0; st.Xa = 0; st.q = Pos{0, 0, 0.f, 0.f, false, false};
         pre_slot = -1;
+        bulk_cnt = 0;
         if (!st.have) return st;
         st.p = uni_i(rm.p[k - kb]);
         st.t = st.p / ge.nscan;
@@ -398,33 +431,32 @@ __global__ __launch_bounds__(ColCfg<N>::NT) void k_cols_gatherwin(const ColArgs 
                     const int Y = Yhi + tid / WC, col = tid % WC;
                     const int X = X0 + col;
                     const bool inb = Y < ge.nz && X >= 0 && X < ge.n;
-                    const c32 val = ft[inb ? ((size_t)Y * ge.n + X) : 0];
-                    pre_val = inb ? val : zero;
+                    pre_val = ft[inb ? ((size_t)Y * ge.n + X) : 0];   // raw: the select waits until prepare_commit, so
+                    pre_inb = inb;                                      // nothing here has to wait for the load
                     pre_slot = (Y % H) * WC + col;
                 }
+            } else if (defer) {
+                bulk_cnt = cnt; bulk_y0 = Yhi; bulk_ft = ft;
             } else {
-                for (int o = tid; o < cnt; o += NT) {
-                    const int Y = Yhi + o / WC, col = o % WC;
-                    const int X = X0 + col;
-                    const bool inb = Y < ge.nz && X >= 0 && X < ge.n;
-                    const c32 val = ft[inb ? ((size_t)Y * ge.n + X) : 0];
-                    const int ws = (Y % H) * WC + col;
-                    win[ws] = inb ? val : zero;
-                    if (ws < WC) win[H * WC + ws] = inb ? val : zero;   // mirror of row 0
-                }
+                bulk_fill(ft, Yhi, cnt);
             }
             Yhi = Rb;
         }
         return st;
     };
     auto prepare_commit = [&]() {
+        if (bulk_cnt > 0) {
+            bulk_fill(bulk_ft, bulk_y0, bulk_cnt);
+            bulk_cnt = 0;
+        }
         if (pre_slot >= 0) {
-            win[pre_slot] = pre_val;
-            if (pre_slot < WC) win[H * WC + pre_slot] = pre_val;   // mirror of row 0
+            const c32 val = pre_inb ? pre_val : zero;
+            win[pre_slot] = val;
+            if (pre_slot < WC) win[H * WC + pre_slot] = val;   // mirror of row 0
         }
     };
     auto prepare = [&](int k, int kend) -> St {
-        St st = prepare_issue(k, kend);
+        St st = prepare_issue(k, kend, std::false_type{});
         prepare_commit();
         return st;
     };
@@ -472,7 +504,7 @@ __global__ __launch_bounds__(ColCfg<N>::NT) void k_cols_gatherwin(const ColArgs 
             } else {
                 __syncthreads();
             }
-            const St cur = prepare_issue(k, ke);   // same decode as st, plus the window update
+            const St cur = prepare_issue(k, ke, std::false_type{});   // same decode as st, plus the window update
             if (SPLIT) {
                 fft.template compute<LAST>(v);
             } else if (P::NSTEP > 1) {
@@ -514,6 +546,7 @@ __global__ __launch_bounds__(ColCfg<N>::NT) void k_cols_gatherwin(const ColArgs 
     }
     St st = prepare(kb, ke);
     __syncthreads();
+    STAMP_DECL
     for (int k = kb; k < ke; ++k) {
         if (MODE == M_FWD && (NM > 1 || st.t != cur_t)) {
             probe_strip(pr, 0, st.t);
@@ -554,7 +587,9 @@ __global__ __launch_bounds__(ColCfg<N>::NT) void k_cols_gatherwin(const ColArgs 
 
         c32 v[E];
         c32 vbase[NM > 1 ? E : 1];   // patch values in step-0 slot order, shared by the NM modes
+        St nx;
         if (MODE == M_FWD) {
+            STAMP(0)      // loop head
             c32 nat[E];
             int slot = slot0;
 #pragma unroll
@@ -564,6 +599,16 @@ __global__ __launch_bounds__(ColCfg<N>::NT) void k_cols_gatherwin(const ColArgs 
                 slot = slot >= H ? slot - H : slot;
             }
             F::from_natural(nat, v);
+#ifdef PTY_STAMPS
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int s2 = 0; s2 < E; ++s2) asm volatile("" : "+v"(v[s2]));
+#endif
+            STAMP(1)      // gather: LDS taps + bilinear weights
+            // split kernel: this thread's share of the rows that slide in for position k + 1 is requested NOW, ahead
+            // of this position's 16 stores -- vector memory operations complete in issue order, so a load issued
+            // behind the stores would wait for all of them to drain to HBM before the window could move on
+            if (SPLIT) nx = prepare_issue(k + 1, ke, std::true_type{});
             if (NM > 1) {
 #pragma unroll
                 for (int s2 = 0; s2 < E; ++s2) vbase[s2] = v[s2];
@@ -575,15 +620,22 @@ __global__ __launch_bounds__(ColCfg<N>::NT) void k_cols_gatherwin(const ColArgs 
             fft.template load<0>(v, j0, [&](int i) { return tile_in[(size_t)i * N + x]; });
         }
         fft.template compute<0>(v);
-        St nx;
         if (SPLIT && MODE == M_FWD) {
             // the radix-16 outputs go straight to rows 16 j0 + k1 of the strip (Stockham step 0)
             c32* tile_out = a.dst + (size_t)st.p * N * N;
+#ifdef PTY_STAMPS
+#pragma unroll
+            for (int s2 = 0; s2 < E; ++s2) asm volatile("" : "+v"(v[s2]));
+#endif
+            STAMP(2)      // probe product + radix-16 step
             fft.template store<0>(v, j0, [&](int i, c32 val) { tile_out[(size_t)i * N + x] = val; });
+            STAMP(3)      // store issue
             __syncthreads();   // every bilinear read of position k is done
-            nx = prepare_issue(k + 1, ke);
+            STAMP(4)      // barrier
             prepare_commit();
+            STAMP(5)      // window update (LDS store of the rows requested above)
             __syncthreads();
+            STAMP(6)      // barrier
             st = nx;
             continue;
         }
@@ -602,7 +654,7 @@ __global__ __launch_bounds__(ColCfg<N>::NT) void k_cols_gatherwin(const ColArgs 
             if (P::NSTEP > 1) {
                 fft.template store<0>(v, j0, [&](int i, c32 val) { lds[i * C + c] = val; });
                 __syncthreads();
-                if (MODE == M_FWD && km == 0) nx = prepare_issue(k + 1, ke);   // window of k is no longer read
+                if (MODE == M_FWD && km == 0) nx = prepare_issue(k + 1, ke, std::false_type{});   // window of k is no longer read
                 fft.template load<1>(v, j0, [&](int i) { return lds[i * C + c]; });
                 if (P::NSTEP > 2) {
                     __syncthreads();
@@ -616,7 +668,7 @@ __global__ __launch_bounds__(ColCfg<N>::NT) void k_cols_gatherwin(const ColArgs 
                 fft.template compute<LAST>(v);
             } else if (MODE == M_FWD && km == 0) {
                 __syncthreads();
-                nx = prepare_issue(k + 1, ke);
+                nx = prepare_issue(k + 1, ke, std::false_type{});
             }
             if (MODE == M_FWD) {
                 c32* tile_out = (NM == 1 ? a.dst : a.dstm[km]) + (size_t)st.p * N * N;
@@ -648,6 +700,7 @@ __global__ __launch_bounds__(ColCfg<N>::NT) void k_cols_gatherwin(const ColArgs 
         st = nx;
     }
     if (MODE == M_ADJ_PRB && cur_t >= 0) flush_probe(cur_t);
+    if (MODE == M_FWD && SPLIT) { STAMP_FLUSH(a.stamps) }
 }
 
 // ---------------------------------------------------------------------------

@@ -197,7 +197,63 @@ struct RowFusedArgs {
     // EP_PROJECT: if set, max |out| (float bits in the low word, as k_cg_absmax leaves it) -- the deterministic
     // adjoint that follows sizes its fixed point from it and skips its own pass over the slot
     double* maxword;
+    // cross-workgroup sums in a fixed order (ptycho_common.hpp); the last workgroup adds the totals to sums
+    // (overwrite = 1: stores them -- the native CG stages, which then need no zero fill)
+    FoldBuf fold;
+    int overwrite;
+    // line search on the device-resident state, single GPU: the last workgroup also replays line_search_sqr on the
+    // totals (ls_decide_dev), which saves the one-thread decision kernel between two passes.  decide = 0: off
+    int decide, decide_which, decide_gamma_word, decide_next;
+    // EP_CROSS: if set, best[0 .. nbest) <- 0 for the arg-max column pass that follows (saves its zero fill)
+    unsigned long long* best_zero;
+    int nbest;
 };
+
+// ---- line_search_sqr's accept / shrink loop on the device (ptycho.py:253-281) -------------------------------
+// A pass prices ngroups x ncand step lengths gamma0 2^-j in one sweep over the two work buffers; candidate j of group
+// grp lands in costs[grp * 17 + j], f(p1) in costs[grp * 17 + ncand].  Accept the first step whose float32 cost is
+// not above f(p1), fail below 1e-32.  which: hint slot; gamma_word: where 0.5 * step goes (ptycho.py:393,461);
+// next_ngroups: size of the pass that follows if this one did not resolve the search (0: none follows).
+__device__ inline void ls_decide_dev(double* __restrict__ st, const int which, const int gamma_word, const int next_ngroups) {
+    if (st[PTYCHO_ST_LS_RESOLVED] != 0.0) return;
+    const int ngroups = (int)st[PTYCHO_ST_LS_NGROUPS];
+    const int ncand = (int)st[PTYCHO_ST_LS_NCAND];
+    int tried = (int)st[PTYCHO_ST_LS_TRIED];
+    double step = st[PTYCHO_ST_LS_GAMMA0];
+    bool done = false;
+    for (int grp = 0; grp < ngroups && !done; ++grp) {
+        const double* c = st + PTYCHO_ST_COSTS + grp * (kMaxCand + 1);
+        const float fp1 = (float)c[ncand];                    // the reference compares float32 costs
+        for (int j = 0; j < ncand; ++j) {
+            if (!((float)c[j] > fp1)) {
+                st[gamma_word] = 0.5 * step;
+                st[PTYCHO_ST_HINT + which] = (double)(tried + j);
+                done = true;
+                break;
+            }
+            if (step < 1e-32) {                               // "Line search failed for conjugate gradient."
+                st[gamma_word] = 0.0;
+                st[PTYCHO_ST_HINT + which] = 14.0;
+                st[PTYCHO_ST_LS_FAILED] += 1.0;
+                done = true;
+                break;
+            }
+            step *= 0.5;
+        }
+        if (!done) tried += ncand;
+    }
+    if (!done && next_ngroups == 0) {   // cannot happen with 2..16 + 16 + 32 + 64 (or 2..16 + 112) step lengths (2^-106 < 1e-32); fail safe
+        st[gamma_word] = 0.0;
+        st[PTYCHO_ST_LS_FAILED] += 1.0;
+        done = true;
+    }
+    st[PTYCHO_ST_LS_RESOLVED] = done ? 1.0 : 0.0;
+    st[PTYCHO_ST_LS_TRIED] = (double)tried;
+    st[PTYCHO_ST_LS_GAMMA0] = step;
+    st[PTYCHO_ST_LS_NCAND] = (double)kMaxCand;
+    st[PTYCHO_ST_LS_NGROUPS] = (double)next_ngroups;
+}
+
 
 // Waves per SIMD the register allocation must leave room for.  Left alone the compiler takes 270..310 registers
 // (VGPR + AGPR) for the two-input stages, i.e. ONE wave per SIMD, and these kernels are bound by their VALU /
@@ -223,6 +279,8 @@ __global__ __launch_bounds__(256, (fused_min_waves<N, EP>())) void k_rows_fused(
     constexpr int NACC = (EP == EP_STATS || EP == EP_STATS_M) ? 2 : (LS ? kMaxCand + 1 : 1);
     __shared__ c32 lds[P::NSTEP > 1 ? B * L::FS : 1];
     __shared__ double red[4 * NACC];
+    __shared__ double vals[EP == EP_CROSS ? 1 : kFoldStride];    // this workgroup's sums, in the layout of the output
+    __shared__ double fscr[EP == EP_CROSS ? 1 : 256];
     __shared__ c32 stash[(EP == EP_CROSS || EP == EP_LINESEARCH_M) ? E * 256 : 1];
     // single-mode line search with several groups of 16 step lengths in ONE sweep: per batch every wave folds its
     // partial costs of a group into these float64 accumulators (one row per wave) instead of keeping 17 registers per
@@ -244,6 +302,7 @@ __global__ __launch_bounds__(256, (fused_min_waves<N, EP>())) void k_rows_fused(
         fft.init(j0, a.table);
     }
     const c32 zero = c32{0.0f, 0.0f};
+    if (EP != EP_CROSS && tid < kFoldStride) vals[tid] = 0.0;
     float acc[NACC];
     c32 acc2[LS ? NACC : 1];   // line search: even / odd pixel partial sums
 #pragma unroll
@@ -271,6 +330,9 @@ __global__ __launch_bounds__(256, (fused_min_waves<N, EP>())) void k_rows_fused(
         sums = a.st + PTYCHO_ST_COSTS;
     }
     if (EP == EP_CROSS && a.gamma_dev) gamma0 = (float)*a.gamma_dev;
+    if (EP == EP_CROSS && a.best_zero) {
+        for (int i = blockIdx.x * 256 + tid; i < a.nbest; i += gridDim.x * 256) a.best_zero[i] = 0ull;
+    }
 
     // forward DFT over x of one row held as step-0 inputs in v; result in natural order
     auto fwd_row = [&](c32* v, c32* nat) {
@@ -567,23 +629,17 @@ __global__ __launch_bounds__(256, (fused_min_waves<N, EP>())) void k_rows_fused(
             double x = 0.0;
 #pragma unroll
             for (int w = 0; w < 4; ++w) x += gacc[(w * kLsGroupsRows + gi) * (kMaxCand + 1) + i];
-            atomicAdd(sums + gi * (kMaxCand + 1) + i, x);
+            vals[o] = x;
         }
-        return;
     }
+    if (EP == EP_CROSS) return;
+    if (EP == EP_STATS_M && !a.sums) return;
+    if (!(EP == EP_LINESEARCH && multi)) {
     if (LS) {
 #pragma unroll
         for (int i = 0; i < NACC; ++i) acc[i] = acc2[i].x + acc2[i].y;
     }
-    if (EP == EP_CROSS) return;
-    if (EP == EP_STATS_M && !a.sums) return;
-    if (EP == EP_PROJECT && a.maxword) {   // one atomicMax per wave (non-negative floats order like unsigned integers)
-        float m = vmax2;
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_down(m, off, 64));
-        if ((tid & 63) == 0) atomicMax(reinterpret_cast<unsigned*>(a.maxword), __float_as_uint(sqrtf(m) * 1.0000002f));
-    }
-    // ---- block reduction (float partials -> double), one atomic per value per workgroup
+    // ---- block reduction (float partials -> double) in a fixed order: shuffle tree per wave, waves in index order
     const int lane = tid & 63, wave = tid >> 6;
 #pragma unroll
     for (int i = 0; i < NACC; ++i) {
@@ -595,10 +651,30 @@ __global__ __launch_bounds__(256, (fused_min_waves<N, EP>())) void k_rows_fused(
     __syncthreads();
     if (tid < NACC) {
         const double x = red[tid] + red[NACC + tid] + red[2 * NACC + tid] + red[3 * NACC + tid];
-        double* out = sums + (LS ? grp * (kMaxCand + 1) : 0);
         if (!LS || tid < ncand || tid == kMaxCand)
-            atomicAdd(out + (LS && tid == kMaxCand ? ncand : tid), x);
+            vals[(LS ? grp * (kMaxCand + 1) : 0) + (LS && tid == kMaxCand ? ncand : tid)] = x;
     }
     __syncthreads();
+    }
     }   // grp
+    // ---- totals over the workgroups in a fixed order; the last workgroup to arrive publishes them ----------
+    int nv = LS ? ngroups * (kMaxCand + 1) : NACC, nmax = 0;
+    if (EP == EP_PROJECT && a.maxword) {   // max |out| rides along as one more value (folded with max)
+        float m = vmax2;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_down(m, off, 64));
+        if ((tid & 63) == 0) fscr[tid >> 6] = (double)(sqrtf(m) * 1.0000002f);
+        __syncthreads();
+        if (tid == 0) vals[1] = fmax(fmax(fscr[0], fscr[1]), fmax(fscr[2], fscr[3]));
+        nv = 2; nmax = 1;
+    }
+    if (!fold_across_workgroups(a.fold, vals, nv, nmax, fscr)) return;
+    const int nsum = nv - nmax;
+    if (tid < nsum) sums[tid] = a.overwrite ? vals[tid] : sums[tid] + vals[tid];
+    if (EP == EP_PROJECT && a.maxword && tid == 0)
+        *reinterpret_cast<unsigned long long*>(a.maxword) = (unsigned long long)__float_as_uint((float)vals[1]);
+    if (LS && a.st && a.decide) {
+        __syncthreads();
+        if (tid == 0) ls_decide_dev(a.st, a.decide_which, a.decide_gamma_word, a.decide_next);
+    }
 }

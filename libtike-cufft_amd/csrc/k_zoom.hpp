@@ -29,7 +29,7 @@ __global__ __launch_bounds__(NT) void k_zoom_argmax(const c32* __restrict__ ip, 
                                                     const double* __restrict__ lz, const int N, const int nc,
                                                     const int ups, int* __restrict__ out,
                                                     const double* __restrict__ coarse, const double up,
-                                                    double* __restrict__ shifts) {
+                                                    double* __restrict__ shifts, float* __restrict__ scan_add) {
     constexpr int RK = kZoomRK;
     constexpr int NW = NT / 64;
     extern __shared__ double2 ybuf[];          // [N][RKC]
@@ -153,8 +153,14 @@ __global__ __launch_bounds__(NT) void k_zoom_argmax(const c32* __restrict__ ip, 
         if (out) out[i] = besti;
         if (shifts) {   // ptycho.py:233-235: shifts + (argmax - dftshift) / upsample_factor
             const double dftshift = (double)(ups / 2);
-            shifts[2 * i] = coarse[2 * i] + ((double)(besti / ups) - dftshift) / up;
-            shifts[2 * i + 1] = coarse[2 * i + 1] + ((double)(besti % ups) - dftshift) / up;
+            const double sy = coarse[2 * i] + ((double)(besti / ups) - dftshift) / up;
+            const double sx = coarse[2 * i + 1] + ((double)(besti % ups) - dftshift) / up;
+            shifts[2 * i] = sy;
+            shifts[2 * i + 1] = sx;
+            if (scan_add) {   // scan[0, :] += shifts (ptycho.py:403), float32 like the reference's in-place add
+                scan_add[2 * i] += (float)sy;
+                scan_add[2 * i + 1] += (float)sx;
+            }
         }
     }
 }
@@ -212,7 +218,7 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 3 : 1)) void k_zoom_mfma(const c32
                                                   const double* __restrict__ lz, const int N, const int nc,
                                                   const int ups, int* __restrict__ out,
                                                   const double* __restrict__ coarse, const double up,
-                                                  double* __restrict__ shifts) {
+                                                  double* __restrict__ shifts, float* __restrict__ scan_add) {
     constexpr int RK = kZoomRK;
     constexpr int NW = NT / 64;
     __shared__ double2 cpart[NW * RK * RK];
@@ -344,8 +350,14 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 3 : 1)) void k_zoom_mfma(const c32
         if (out) out[i] = besti;
         if (shifts) {   // ptycho.py:233-235: shifts + (argmax - dftshift) / upsample_factor
             const double dftshift = (double)(ups / 2);
-            shifts[2 * i] = coarse[2 * i] + ((double)(besti / ups) - dftshift) / up;
-            shifts[2 * i + 1] = coarse[2 * i + 1] + ((double)(besti % ups) - dftshift) / up;
+            const double sy = coarse[2 * i] + ((double)(besti / ups) - dftshift) / up;
+            const double sx = coarse[2 * i + 1] + ((double)(besti % ups) - dftshift) / up;
+            shifts[2 * i] = sy;
+            shifts[2 * i + 1] = sx;
+            if (scan_add) {   // scan[0, :] += shifts (ptycho.py:403), float32 like the reference's in-place add
+                scan_add[2 * i] += (float)sy;
+                scan_add[2 * i + 1] += (float)sx;
+            }
         }
     }
 }

@@ -18,6 +18,27 @@ struct ColCfg {
     static constexpr int NT = T * C;            // threads per workgroup
 };
 
+// ---- deterministic adjoints: fixed-point accumulation (ColArgs::det_acc) ----------------------------
+// scale = 2^p with  2^p * bound < 2^(62 - head),  bound = max|g| * max|prb or psi| * ndet >= any single window sum / probe
+// sum contribution's magnitude (|near| <= ndet^2 max|g|, times c = 1/ndet, times |prb|); head = bits of headroom for the
+// additions per element.  words: float bits of max|g| and max|other| (k_cg_absmax).  A pure function of the two words:
+// the column kernel that accumulates and the kernel that folds the image into the output both evaluate it.
+struct DetScale {
+    const double* word_g;
+    const double* word_o;
+    int ndet;
+    int head;
+};
+__device__ __forceinline__ float absmax_of(const double* word) { return __uint_as_float(*reinterpret_cast<const unsigned*>(word)); }
+__device__ __forceinline__ float det_scale_of(const DetScale& d) {
+    const float bound = absmax_of(d.word_g) * absmax_of(d.word_o) * (float)d.ndet;
+    int e = 0;
+    frexpf(bound > 0.0f ? bound : 1.0f, &e);              // bound < 2^e
+    int p = 62 - d.head - e;
+    p = p > 120 ? 120 : (p < -120 ? -120 : p);
+    return ldexpf(1.0f, p);
+}
+
 struct ColArgs {
     const c32* src;     // FWD: object f; ADJ_*: chunk scratch (tile index k - k_begin); PLAIN: tiles
     c32* dst;           // FWD: farplane g; ADJ_OBJ: object f; ADJ_PRB: probe; PLAIN: tiles
@@ -36,10 +57,27 @@ struct ColArgs {
     c32* dstm[4];
     // deterministic adjoints (option "deterministic"): the per-workgroup sums are added to a 64-bit fixed-point
     // image with INTEGER atomics (associative, so the result does not depend on the arrival order) instead of
-    // float atomics on dst; *det_scale is the power of two that converts a float to that fixed point
+    // float atomics on dst; det_scale_of(det) is the power of two that converts a float to that fixed point
     long long* det_acc;
-    const float* det_scale;
+    DetScale det;
+#ifdef PTY_STAMPS
+    unsigned long long* stamps;   // diagnostic build only (tools/stamps.py): per-phase cycle totals, 12 words per kernel role
+#endif
 };
+
+// In-kernel phase stamps (cdna_hip_programming.md section 7): compiled in only with -DPTY_STAMPS, a diagnostic build
+// that is never shipped; every wave adds the shader cycles it spent in each phase to ColArgs::stamps.
+#ifdef PTY_STAMPS
+#define STAMP_DECL unsigned long long st_t_ = __builtin_amdgcn_s_memtime(), st_acc_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#define STAMP(i) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); st_acc_[i] += now_ - st_t_; st_t_ = now_; }
+#define STAMP_DRAIN() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#define STAMP_FLUSH(ptr) if ((ptr) && (threadIdx.x & 63) == 0) { for (int i_ = 0; i_ < 12; ++i_) atomicAdd((ptr) + i_, st_acc_[i_]); }
+#else
+#define STAMP_DECL
+#define STAMP(i)
+#define STAMP_DRAIN()
+#define STAMP_FLUSH(ptr)
+#endif
 
 struct RowArgs {
     const c32* src;
@@ -131,4 +169,57 @@ template <int T>
 __device__ __forceinline__ void row_sync() {
     if constexpr (T <= 64 && 64 % T == 0) wave_lds_fence();
     else __syncthreads();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Order-free reductions across workgroups.  The CG scalars (a, b, costs, Dai-Yuan sums: ptycho.py:342-343,274-276,
+// 370-371) decide float32 accept / reject comparisons, so their value must not depend on the order in which
+// workgroups finish (float64 atomicAdd does).  Every workgroup stores its partial values in its own row of a scratch
+// table and takes a ticket; the workgroup that arrives last adds the rows in index order (a fixed tree) and gets the
+// totals.  Hand-off = write-through (sc1) 8-byte stores, drained, then one agent-scope ticket add per workgroup; the
+// last arriver reads the rows with sc1 loads (MI355X_MICROARCH.md, "Valid forms", row 1 of the hand-off table).
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int kFoldStride = 128;   // values per workgroup row (>= 7 groups x 17 line-search costs)
+struct FoldBuf {
+    unsigned long long* part;   // [rows][kFoldStride] doubles as bits; rows >= gridDim.x of every kernel that folds
+    unsigned* ticket;           // zero between kernels
+};
+
+// Called by ALL threads of EVERY workgroup of the grid (256 threads), once per kernel, with the workgroup's nv <=
+// kFoldStride partial values in LDS vals[].  Returns true in the last workgroup to arrive, with vals[0 .. nv) replaced
+// by the totals (sum; the last nmax values: maximum) and visible to all its threads.  scratch: 256 doubles of LDS.
+__device__ __forceinline__ bool fold_across_workgroups(const FoldBuf fb, double* vals, const int nv, const int nmax, double* scratch) {
+    __shared__ int fold_last;
+    const int tid = threadIdx.x;
+    unsigned long long* mine = fb.part + (size_t)blockIdx.x * kFoldStride;
+    __syncthreads();
+    for (int i = tid; i < nv; i += 256)
+        __hip_atomic_store(mine + i, (unsigned long long)__double_as_longlong(vals[i]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) fold_last = atomicAdd(fb.ticket, 1u) == gridDim.x - 1 ? 1 : 0;
+    __syncthreads();
+    if (!fold_last) return false;
+    int nvp = 1;
+    while (nvp < nv) nvp <<= 1;
+    const int G = 256 / nvp;            // threads per value
+    const int v = tid % nvp, g = tid / nvp;
+    const bool is_max = v >= nv - nmax;
+    double acc = 0.0;
+    if (v < nv && g < G) {
+        for (unsigned b = (unsigned)g; b < gridDim.x; b += (unsigned)G) {
+            const double x = __longlong_as_double((long long)__hip_atomic_load(fb.part + (size_t)b * kFoldStride + v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            acc = is_max ? fmax(acc, x) : acc + x;
+        }
+    }
+    scratch[tid] = acc;
+    __syncthreads();
+    if (tid < nv) {
+        double t = scratch[tid];
+        for (int gg = 1; gg < G; ++gg) t = is_max ? fmax(t, scratch[gg * nvp + tid]) : t + scratch[gg * nvp + tid];
+        vals[tid] = t;
+    }
+    if (tid == 0) *fb.ticket = 0u;      // ready for the next kernel on the stream
+    __syncthreads();
+    return true;
 }

@@ -90,14 +90,25 @@ struct ptycho_handle_s {
     int use_split = 1;        // ndet = 256: one radix-16 step of the DFT over y runs in the row pass
     int deterministic = 0;    // 1: adjoints accumulate in 64-bit fixed point (integer atomics): bitwise reproducible results
     long long* det_acc = nullptr;   // fixed-point image, 2 words per object (or probe) element, kept zero between calls
-    float* det_scale = nullptr;     // device: power of two float -> fixed point
     double* det_words = nullptr;    // device: max |g|, max |probe or object| as float bits (k_cg_absmax)
+    DetScale last_det{};            // scale of the adjoint whose sums sit in det_acc (k_det_finish / k_cg_dy_reduce fold them in)
+    bool det_pending = false;       // native CG stages: the gradient is still in det_acc (option "defer_finish")
+    int defer_finish = 0;           // 1: ptycho_cg_obj_grad / prb_grad leave the gradient in det_acc for ptycho_cg_*_dir
+    int ls_fused_decide = 0;        // 1: line-search passes decide on their own totals (single GPU: nothing to all-reduce)
+    bool max_prb_valid = false, max_psi_valid = false;   // state[MAX_PRB / MAX_PSI] were set by the *_grad stage of this step
+    FoldBuf fold{};                 // fixed-order cross-workgroup sums (ptycho_common.hpp): n_cu * 8 rows + ticket
+    int fold_rows = 0;
     int compact_modes = 0;    // multi-mode CG: 0 = slot pairs (2k, 2k+1); M = compact layout A(k) = k, one shared B = M
     int sort_chunks = 1;      // position order is chunk-major over this many equal position ranges (chunked line search)
     int use_fused = 0;        // ndet = 256 forward as one launch (k_fwd_fused256): 0 off (default: measured slower), 1 / 2 class tiles per pass
     c32* prbp = nullptr;      // fused forward: c * probe in a zero-bordered ndet x ndet frame, per angle
     int trust_order = 0;      // 1: caller vouches that scan is unchanged since the last sort
+    int native_order = 0;     // 1: the native CG stages are running and track scan themselves (ptycho_cg_obj_finish re-sorts
+                              // after it moved the positions); cleared by ptycho_fwd / ptycho_adj, whose callers own trust_order
     const float* order_scan = nullptr;   // scan pointer the current order was computed from
+#ifdef PTY_STAMPS
+    unsigned long long* stamps = nullptr;   // diagnostic build: 24 words (forward column pass, object adjoint column pass)
+#endif
     int device = 0;
     int n_cu = 256;
     bool freed = false;
@@ -186,6 +197,9 @@ int launch_adjwin(ptycho_handle h, ColArgs a, hipStream_t st, int wg_target = 0)
     nseg = (np + seglen - 1) / seglen;
     static const int nt_mode_a = std::getenv("PTYCHO_HIP_NT") ? std::atoi(std::getenv("PTYCHO_HIP_NT")) : 0;
     a.nt = nt_mode_a;
+#ifdef PTY_STAMPS
+    a.stamps = h->stamps;
+#endif
     {
         ProfSpan ps(h, K_COLS_ADJ_OBJ, st);
         hipLaunchKernelGGL((k_cols_adjwin<N, SPLIT>), dim3((unsigned)(a.nstrips * nseg)), dim3(CC::NT), 0, st, a, seglen);
@@ -216,6 +230,9 @@ int launch_gatherwin(ptycho_handle h, ColArgs a, hipStream_t st, int wg_target =
     }
     static const int nt_mode_g = std::getenv("PTYCHO_HIP_NT") ? std::atoi(std::getenv("PTYCHO_HIP_NT")) : 0;
     a.nt = nt_mode_g;
+#ifdef PTY_STAMPS
+    a.stamps = h->stamps;
+#endif
     {
         ProfSpan ps(h, MODE == M_FWD ? K_COLS_FWD : K_COLS_ADJ_PRB, st);
         hipLaunchKernelGGL((k_cols_gatherwin<N, MODE, SPLIT>), dim3((unsigned)(a.nstrips * nseg)), dim3(CC::NT), 0, st, a, seglen);
@@ -338,39 +355,46 @@ int do_fwd(ptycho_handle h, c32* g, const c32* f, const float* scan, const c32* 
 
 
 // ---- deterministic adjoints (option "deterministic"): set-up before / fold-in after the column pass ----
+inline unsigned fold_grid(ptycho_handle h, long long n, int per_cu) {   // grid of a kernel that folds: <= fold_rows workgroups
+    long long g = (n + 255) / 256;
+    long long cap = (long long)h->n_cu * per_cu;
+    if (cap > h->fold_rows) cap = h->fold_rows;
+    if (g > cap) g = cap;
+    return (unsigned)(g < 1 ? 1 : g);
+}
 int det_begin(ptycho_handle h, ColArgs& ca, const c32* gsrc, long long gcount, const c32* other, long long ocount, int flg, hipStream_t st,
-              const double* known_gmax = nullptr) {   // known_gmax: max |gsrc| is already on the device (k_cg_absmax format)
+              const double* known_gmax = nullptr,   // max |gsrc| / max |other| are already on the device (k_cg_absmax format)
+              const double* known_omax = nullptr) {
     const Geom& ge = h->ge;
     const size_t nobj = (size_t)ge.ptheta * ge.nz * ge.n, nprb = (size_t)ge.ptheta * ge.nprb * ge.nprb;
     if (!h->det_acc) {
         const size_t words = 2 * (nobj > nprb ? nobj : nprb);
         HIP_TRY(hipMalloc((void**)&h->det_acc, words * sizeof(long long)));
         HIP_TRY(hipMemset(h->det_acc, 0, words * sizeof(long long)));
-        HIP_TRY(hipMalloc((void**)&h->det_scale, sizeof(float)));
         HIP_TRY(hipMalloc((void**)&h->det_words, 2 * sizeof(double)));
+        HIP_TRY(hipMemset(h->det_words, 0, 2 * sizeof(double)));
     }
-    HIP_TRY(hipMemsetAsync(h->det_words, 0, 2 * sizeof(double), st));
-    long long gg = (gcount + 255) / 256;
-    if (gg > (long long)h->n_cu * 16) gg = (long long)h->n_cu * 16;
-    if (!known_gmax) hipLaunchKernelGGL(k_cg_absmax, dim3((unsigned)gg), dim3(256), 0, st, gsrc, gcount, h->det_words);
-    long long go = (ocount + 255) / 256;
-    if (go > (long long)h->n_cu * 4) go = (long long)h->n_cu * 4;
-    hipLaunchKernelGGL(k_cg_absmax, dim3((unsigned)go), dim3(256), 0, st, other, ocount, h->det_words + 1);
+    if (!known_gmax) hipLaunchKernelGGL(k_cg_absmax, dim3(fold_grid(h, gcount, 8)), dim3(256), 0, st, (c32*)gsrc, gcount, h->det_words,
+                                        (double*)nullptr, (const double*)nullptr, h->fold);
+    if (!known_omax) hipLaunchKernelGGL(k_cg_absmax, dim3(fold_grid(h, ocount, 4)), dim3(256), 0, st, (c32*)other, ocount, h->det_words + 1,
+                                        (double*)nullptr, (const double*)nullptr, h->fold);
+    HIP_TRY(hipGetLastError());
     // additions per element: every position of an angle may touch it, four bilinear taps (object) / once (probe)
     const long long nadd = flg == 0 ? 4ll * ge.nscan : (long long)ge.nscan;
-    hipLaunchKernelGGL(k_det_scale, dim3(1), dim3(1), 0, st, known_gmax ? known_gmax : (const double*)h->det_words,
-                       (const double*)(h->det_words + 1), ge.ndet, nadd, h->det_scale);
-    HIP_TRY(hipGetLastError());
+    int head = 1;
+    while ((1ll << head) < nadd && head < 30) ++head;
+    h->last_det = DetScale{known_gmax ? known_gmax : (const double*)h->det_words,
+                           known_omax ? known_omax : (const double*)(h->det_words + 1), ge.ndet, head};
     ca.det_acc = h->det_acc;
-    ca.det_scale = h->det_scale;
+    ca.det = h->last_det;
     return PTYCHO_OK;
 }
-int det_end(ptycho_handle h, c32* dst, int flg, hipStream_t st) {
+int det_end(ptycho_handle h, c32* dst, int flg, hipStream_t st, int add = 1) {
     const Geom& ge = h->ge;
     const long long n = flg == 0 ? (long long)ge.ptheta * ge.nz * ge.n : (long long)ge.ptheta * ge.nprb * ge.nprb;
     long long g = (n + 255) / 256;
     if (g > (long long)h->n_cu * 4) g = (long long)h->n_cu * 4;
-    hipLaunchKernelGGL(k_det_finish, dim3((unsigned)g), dim3(256), 0, st, dst, h->det_acc, n, (const float*)h->det_scale);
+    hipLaunchKernelGGL(k_det_finish, dim3((unsigned)g), dim3(256), 0, st, dst, h->det_acc, n, h->last_det, add);
     HIP_TRY(hipGetLastError());
     return PTYCHO_OK;
 }
@@ -408,7 +432,7 @@ int do_adj(ptycho_handle h, c32* f, const c32* g, const float* scan, c32* prb, i
         ColArgs ca{};
         ca.src = h->scratch; ca.scan = scan; ca.table = h->table; ca.ge = ge;
         ca.order = h->order; ca.k_begin = (int)k0; ca.k_end = (int)k1; ca.strip0 = strip0; ca.nstrips = nstrips;
-        ca.det_acc = det.det_acc; ca.det_scale = det.det_scale;
+        ca.det_acc = det.det_acc; ca.det = det.det;
         if constexpr (N == 256) {
             if (split) {
                 if (flg == 0) {
@@ -488,8 +512,7 @@ int project_maxword(ptycho_handle h, int dst_slot, RowFusedArgs& a, hipStream_t 
         HIP_TRY(hipMalloc((void**)&h->slot_maxw, ptycho_handle_s::kSlots * sizeof(double)));
         HIP_TRY(hipMemset(h->slot_maxw, 0, ptycho_handle_s::kSlots * sizeof(double)));
     }
-    HIP_TRY(hipMemsetAsync(h->slot_maxw + dst_slot, 0, sizeof(double), st));
-    a.maxword = h->slot_maxw + dst_slot;
+    a.maxword = h->slot_maxw + dst_slot;   // stored (not accumulated) by the stage's last workgroup
     return PTYCHO_OK;
 }
 
@@ -518,8 +541,11 @@ int do_cg_fwd_cols(ptycho_handle h, int slot, const c32* f, const float* scan, c
     return rc;
 }
 
+// finish: 1 = add the result to f / prb (public entry point: the caller zero-filled it); 0 = store it (no zero fill
+// needed); -1 = leave it in the fixed-point image for ptycho_cg_*_dir (deterministic option only)
 template <int N>
-int do_cg_adj_cols(ptycho_handle h, int slot, c32* f, const float* scan, c32* prb, int flg, hipStream_t st) {
+int do_cg_adj_cols(ptycho_handle h, int slot, c32* f, const float* scan, c32* prb, int flg, hipStream_t st,
+                   const double* known_omax = nullptr, int finish = 1) {
     const Geom& ge = h->ge;
     const long long total = (long long)ge.ptheta * ge.nscan;
     int strip0, nstrips;
@@ -534,7 +560,7 @@ int do_cg_adj_cols(ptycho_handle h, int slot, c32* f, const float* scan, c32* pr
         if (!window) return fail(PTYCHO_ERR_ARG, "option deterministic needs the windowed adjoint kernels (ndet <= 512)");
         rc = det_begin(h, ca, h->work[slot], total * N * N, flg == 0 ? prb : f,
                        flg == 0 ? (long long)ge.ptheta * ge.nprb * ge.nprb : (long long)ge.ptheta * ge.nz * ge.n, flg, st,
-                       h->slot_max_ok[slot] ? h->slot_maxw + slot : nullptr);
+                       h->slot_max_ok[slot] ? h->slot_maxw + slot : nullptr, known_omax);
         if (rc) return rc;
     }
     if (flg == 0) {
@@ -552,7 +578,10 @@ int do_cg_adj_cols(ptycho_handle h, int slot, c32* f, const float* scan, c32* pr
             rc = launch_cols<N, +1, M_ADJ_PRB>(h, ca, st);
         }
     }
-    if (!rc && h->deterministic) rc = det_end(h, flg == 0 ? f : prb, flg, st);
+    if (!rc && h->deterministic) {
+        if (finish < 0) h->det_pending = true;
+        else rc = det_end(h, flg == 0 ? f : prb, flg, st, finish);
+    }
     return rc;
 }
 
@@ -567,6 +596,8 @@ int do_cg_rows(ptycho_handle h, RowFusedArgs a, hipStream_t st) {
     a.xa = strip0 * C; a.xb = (strip0 + nstrips) * C;
     long long nb = (a.nrows + B - 1) / B;
     long long grid = nb < (long long)h->n_cu * 8 ? nb : (long long)h->n_cu * 8;
+    if (grid > h->fold_rows) grid = h->fold_rows;
+    a.fold = h->fold;
     {
         ProfSpan ps(h, (EP == EP_STATS || EP == EP_STATS_M) ? K_ROWS_STATS : EP == EP_PROJECT ? K_ROWS_PROJECT : (EP == EP_LINESEARCH || EP == EP_LINESEARCH_M) ? K_ROWS_LINESEARCH : K_ROWS_CROSS, st);
         hipLaunchKernelGGL((k_rows_fused<N, EP>), dim3((unsigned)grid), dim3(256), 0, st, a);
@@ -671,7 +702,7 @@ int sort_positions(ptycho_handle h, const float* scan, hipStream_t st) {
     const int total = h->ge.ptheta * h->ge.nscan;
     // The order depends only on the scan positions.  A caller that knows they have not
     // changed since the previous call on this handle (option "trust_order") skips the sort.
-    if (h->trust_order && h->order_scan == scan) return PTYCHO_OK;
+    if ((h->trust_order || h->native_order) && h->order_scan == scan) return PTYCHO_OK;
     h->order_scan = scan;
     const int iblocks = (total + 255) / 256;
     int nslices = (2 * h->n_cu + iblocks - 1) / iblocks;
@@ -698,8 +729,8 @@ int alloc_sort(ptycho_handle h) {
 
 void release(ptycho_handle h) {
     if (h->slot_maxw) { (void)hipFree(h->slot_maxw); h->slot_maxw = nullptr; }
-    void* ptrs[] = {h->det_acc, h->det_scale, h->det_words, h->bs_chirp, h->bs_hfilt, h->table, h->scratch, h->order, h->sort_counts, h->zoom_phase, h->prbp, h->reg_ip, h->reg_best, h->reg_shifts};
-    h->det_acc = nullptr; h->det_scale = nullptr; h->det_words = nullptr; h->zoom_phase = nullptr; h->prbp = nullptr; h->bs_chirp = nullptr; h->bs_hfilt = nullptr; h->reg_ip = nullptr; h->reg_best = nullptr; h->reg_shifts = nullptr;
+    void* ptrs[] = {h->det_acc, (void*)h->fold.part, (void*)h->fold.ticket, h->det_words, h->bs_chirp, h->bs_hfilt, h->table, h->scratch, h->order, h->sort_counts, h->zoom_phase, h->prbp, h->reg_ip, h->reg_best, h->reg_shifts};
+    h->det_acc = nullptr; h->fold.part = nullptr; h->fold.ticket = nullptr; h->det_words = nullptr; h->zoom_phase = nullptr; h->prbp = nullptr; h->bs_chirp = nullptr; h->bs_hfilt = nullptr; h->reg_ip = nullptr; h->reg_best = nullptr; h->reg_shifts = nullptr;
     for (auto& w : h->work) { if (w) (void)hipFree(w); w = nullptr; }
     for (void* q : ptrs)
         if (q) (void)hipFree(q);
@@ -714,6 +745,20 @@ void release(ptycho_handle h) {
 extern "C" {
 
 const char* ptycho_last_error(void) { return g_err.c_str(); }
+#ifdef PTY_STAMPS
+// diagnostic build only: read and clear the in-kernel phase stamps (tools/stamps.py)
+int ptycho_debug_stamps(ptycho_handle h, unsigned long long* out24) {
+    if (!h || !out24) return PTYCHO_ERR_ARG;
+    if (!h->stamps) {
+        if (hipMalloc((void**)&h->stamps, 24 * sizeof(unsigned long long)) != hipSuccess) return PTYCHO_ERR_HIP;
+        (void)hipMemset(h->stamps, 0, 24 * sizeof(unsigned long long));
+    }
+    if (hipDeviceSynchronize() != hipSuccess) return PTYCHO_ERR_HIP;
+    (void)hipMemcpy(out24, h->stamps, 24 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+    (void)hipMemset(h->stamps, 0, 24 * sizeof(unsigned long long));
+    return PTYCHO_OK;
+}
+#endif
 const char* ptycho_version(void) { return "ptychohip 0.3 (gfx950)"; }
 
 int ptycho_create(ptycho_handle* out, size_t ptheta, size_t nz, size_t n, size_t nscan, size_t ndet, size_t nprb) {
@@ -791,6 +836,15 @@ int ptycho_create(ptycho_handle* out, size_t ptheta, size_t nz, size_t n, size_t
     if (env) h->use_fused = std::atoi(env);
 
     h->chunk = default_chunk(h->ge);
+    h->fold_rows = h->n_cu * 8 > 2048 ? h->n_cu * 8 : 2048;
+    e = hipMalloc((void**)&h->fold.part, (size_t)h->fold_rows * kFoldStride * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMalloc((void**)&h->fold.ticket, 64);
+    if (e == hipSuccess) e = hipMemset(h->fold.ticket, 0, 64);
+    if (e != hipSuccess) {
+        release(h);
+        delete h;
+        return fail(PTYCHO_ERR_HIP, std::string("fold scratch: ") + hipGetErrorString(e));
+    }
     int rc = alloc_sort(h);   // the adjoint's scratch (up to 4 GiB) is allocated by the first ptycho_adj call
     if (rc) {
         release(h);
@@ -848,6 +902,7 @@ int ptycho_set_option(ptycho_handle h, const char* name, long long value) {
     }
     if (std::strcmp(name, "trust_order") == 0) {
         h->trust_order = value != 0;
+        h->native_order = 0;
         if (!h->trust_order) h->order_scan = nullptr;
         return PTYCHO_OK;
     }
@@ -869,6 +924,15 @@ int ptycho_set_option(ptycho_handle h, const char* name, long long value) {
     }
     if (std::strcmp(name, "fused") == 0) {
         h->use_fused = (int)value;
+        return PTYCHO_OK;
+    }
+    if (std::strcmp(name, "defer_finish") == 0) {
+        h->defer_finish = value != 0;
+        h->det_pending = false;
+        return PTYCHO_OK;
+    }
+    if (std::strcmp(name, "ls_fused_decide") == 0) {
+        h->ls_fused_decide = value != 0;
         return PTYCHO_OK;
     }
     return fail(PTYCHO_ERR_ARG, std::string("unknown option ") + name);
@@ -904,6 +968,7 @@ int ptycho_fwd(ptycho_handle h, void* g, const void* f, const void* scan, const 
     if (rc) return rc;
     if (!g || !f || !scan || !prb) return fail(PTYCHO_ERR_ARG, "null operand");
     hipStream_t st = (hipStream_t)stream;
+    h->native_order = 0;
     if (h->bs_m) { PTY_DISPATCH(h->bs_m, (do_fwd_generic<NN>(h, (c32*)g, (const c32*)f, (const float*)scan, (const c32*)prb, st))); }
     PTY_DISPATCH(h->ge.ndet, (do_fwd<NN>(h, (c32*)g, (const c32*)f, (const float*)scan, (const c32*)prb, st)));
 }
@@ -913,6 +978,7 @@ int ptycho_adj(ptycho_handle h, void* f, const void* g, const void* scan, void* 
     if (rc) return rc;
     if (!g || !f || !scan || !prb) return fail(PTYCHO_ERR_ARG, "null operand");
     if (flg != 0 && flg != 1) return fail(PTYCHO_ERR_ARG, "flg must be 0 (object) or 1 (probe)");
+    h->native_order = 0;
     if (!h->scratch) {
         rc = alloc_scratch(h);
         if (rc) return rc;
@@ -1060,14 +1126,14 @@ int ptycho_fft2(ptycho_handle h, void* dst, const void* src, size_t nbatch, int 
 }  // extern "C"
 
 template <int N>
-int do_cg_argmax(ptycho_handle h, int slot, unsigned long long* best, hipStream_t st) {
+int do_cg_argmax(ptycho_handle h, int slot, unsigned long long* best, hipStream_t st, bool zeroed = false) {
     using CC = ColCfg<N>;
     const int npos = h->ge.ptheta * h->ge.nscan;
     constexpr int nstrips = N / CC::C;
     int ng = (h->n_cu * 8) / nstrips;
     if (ng < 1) ng = 1;
     if (ng > npos) ng = npos;
-    HIP_TRY(hipMemsetAsync(best, 0, (size_t)npos * sizeof(unsigned long long), st));
+    if (!zeroed) HIP_TRY(hipMemsetAsync(best, 0, (size_t)npos * sizeof(unsigned long long), st));
     {
         ProfSpan ps(h, K_COLS_ARGMAX, st);
         hipLaunchKernelGGL((k_cols_argmax<N>), dim3((unsigned)(nstrips * ng)), dim3(CC::NT), 0, st,
@@ -1105,8 +1171,18 @@ extern "C" int ptycho_cg_argmax(ptycho_handle h, int slot, void* best, void* str
     PTY_DISPATCH(h->ge.ndet, (do_cg_argmax<NN>(h, slot, (unsigned long long*)best, st)));
 }
 
+namespace {
+int zoom_impl(ptycho_handle h, const void* image_product, const void* best, const void* vt,
+              const void* lz, int nc, int ups, double upsample_factor, void* shifts, float* scan_add, void* stream);
+}
 extern "C" int ptycho_cg_zoom(ptycho_handle h, const void* image_product, const void* best, const void* vt,
                               const void* lz, int nc, int ups, double upsample_factor, void* shifts, void* stream) {
+    return zoom_impl(h, image_product, best, vt, lz, nc, ups, upsample_factor, shifts, nullptr, stream);
+}
+namespace {
+// scan_add: scan[0, :] += shifts (ptycho.py:403) by the kernel that finds them (native CG stages)
+int zoom_impl(ptycho_handle h, const void* image_product, const void* best, const void* vt,
+              const void* lz, int nc, int ups, double upsample_factor, void* shifts, float* scan_add, void* stream) {
     int rc = check_handle(h);
     if (rc) return rc;
     if (!image_product) {   // NULL: work slot 2 (see ptycho_cg_cross)
@@ -1138,24 +1214,25 @@ extern "C" int ptycho_cg_zoom(ptycho_handle h, const void* image_product, const 
         int* none = nullptr;
         if (N % 64 == 0 && !no_mfma) {
             if (N <= 256)
-                hipLaunchKernelGGL((k_zoom_mfma<256>), dim3((unsigned)npos), dim3(256), 0, st, ip, ppx, ppy, pv, pl, N, nc, ups, none, coarse, upsample_factor, (double*)shifts);
+                hipLaunchKernelGGL((k_zoom_mfma<256>), dim3((unsigned)npos), dim3(256), 0, st, ip, ppx, ppy, pv, pl, N, nc, ups, none, coarse, upsample_factor, (double*)shifts, scan_add);
             else if (N <= 512)
-                hipLaunchKernelGGL((k_zoom_mfma<512>), dim3((unsigned)npos), dim3(512), 0, st, ip, ppx, ppy, pv, pl, N, nc, ups, none, coarse, upsample_factor, (double*)shifts);
+                hipLaunchKernelGGL((k_zoom_mfma<512>), dim3((unsigned)npos), dim3(512), 0, st, ip, ppx, ppy, pv, pl, N, nc, ups, none, coarse, upsample_factor, (double*)shifts, scan_add);
             else
-                hipLaunchKernelGGL((k_zoom_mfma<1024>), dim3((unsigned)npos), dim3(1024), 0, st, ip, ppx, ppy, pv, pl, N, nc, ups, none, coarse, upsample_factor, (double*)shifts);
+                hipLaunchKernelGGL((k_zoom_mfma<1024>), dim3((unsigned)npos), dim3(1024), 0, st, ip, ppx, ppy, pv, pl, N, nc, ups, none, coarse, upsample_factor, (double*)shifts, scan_add);
         } else if (N <= 256)
             hipLaunchKernelGGL((k_zoom_argmax<256, 8>), dim3((unsigned)npos), dim3(256), (size_t)N * 8 * sizeof(double2), st,
-                               ip, ppx, ppy, pv, pl, N, nc, ups, none, coarse, upsample_factor, (double*)shifts);
+                               ip, ppx, ppy, pv, pl, N, nc, ups, none, coarse, upsample_factor, (double*)shifts, scan_add);
         else if (N <= 512)
             hipLaunchKernelGGL((k_zoom_argmax<512, 4>), dim3((unsigned)npos), dim3(512), (size_t)N * 4 * sizeof(double2), st,
-                               ip, ppx, ppy, pv, pl, N, nc, ups, none, coarse, upsample_factor, (double*)shifts);
+                               ip, ppx, ppy, pv, pl, N, nc, ups, none, coarse, upsample_factor, (double*)shifts, scan_add);
         else
             hipLaunchKernelGGL((k_zoom_argmax<1024, 2>), dim3((unsigned)npos), dim3(1024), (size_t)N * 2 * sizeof(double2), st,
-                               ip, ppx, ppy, pv, pl, N, nc, ups, none, coarse, upsample_factor, (double*)shifts);
+                               ip, ppx, ppy, pv, pl, N, nc, ups, none, coarse, upsample_factor, (double*)shifts, scan_add);
     }
     HIP_TRY(hipGetLastError());
     return PTYCHO_OK;
 }
+}  // namespace
 
 
 // ---------------------------------------------------------------------------------------------------
@@ -1170,23 +1247,36 @@ inline unsigned small_grid(ptycho_handle h, long long n) {
     return (unsigned)(g < 1 ? 1 : g);
 }
 
+// One line-search pass over slots 0 / 1 on the device-resident state.  decide_next >= 0: the pass's last workgroup also
+// replays line_search_sqr on the totals and sizes the pass that follows (single GPU); < 0: the caller all-reduces the
+// costs and calls k_cg_ls_decide.
 template <int N>
-int do_ls_pass(ptycho_handle h, const float* data, const double* ab, double* state, hipStream_t st) {
+int do_ls_pass(ptycho_handle h, const float* data, const double* ab, double* state, hipStream_t st, int which, int decide_next) {
     RowFusedArgs a{};
     a.s1 = h->work[0]; a.s2 = h->work[1]; a.data = data; a.ab = ab; a.st = state;
     a.sums = state + PTYCHO_ST_COSTS; a.gamma0 = 1.0f; a.ncand = kMaxCand;
+    a.overwrite = 1;
+    a.decide = decide_next >= 0 ? 1 : 0;
+    a.decide_which = which;
+    a.decide_gamma_word = which == 0 ? (int)PTYCHO_ST_GAMMA_PSI : (int)PTYCHO_ST_GAMMA_PRB;
+    a.decide_next = decide_next;
     return do_cg_rows<N, EP_LINESEARCH>(h, a, st);
 }
-int ls_pass(ptycho_handle h, const void* data, int use_ab, double* state, hipStream_t st) {
+int ls_pass(ptycho_handle h, const void* data, int use_ab, double* state, hipStream_t st, int which, int decide_next) {
     if (!slot_ready(h, 0) || !slot_ready(h, 1)) return fail(PTYCHO_ERR_ARG, "work slot is empty");
     const double* ab = use_ab ? state + PTYCHO_ST_A : nullptr;
-    PTY_DISPATCH(h->ge.ndet, (do_ls_pass<NN>(h, (const float*)data, ab, state, st)));
+    PTY_DISPATCH(h->ge.ndet, (do_ls_pass<NN>(h, (const float*)data, ab, state, st, which, decide_next)));
 }
+// sizes (groups of 16 step lengths) of the pass that ptycho_cg_ls_next(pass) issues: <= 16 step lengths first (sized from the
+// last accepted index), then 16, 32, 64 more: 2^-106 < 1e-32 is covered.  For callers that pay a collective per pass:
+// 6 then 7 (32, then the 80 that are left), or 5 (all 112 at once).
+constexpr int kLsNext[8] = {0, 1, 2, 4, 0, kLsGroupsMax, 2, 5};
 
 template <int N>
 int do_cross_dev(ptycho_handle h, const double* gamma_dev, hipStream_t st, int s1_slot) {
     RowFusedArgs a{};
     a.s1 = h->work[s1_slot]; a.s2 = h->work[1]; a.out = h->work[1]; a.ip = h->reg_ip; a.gamma_dev = gamma_dev;
+    a.best_zero = h->reg_best; a.nbest = h->ge.ptheta * h->ge.nscan;   // the arg-max pass that follows finds them cleared
     h->slot_max_ok[1] = false;
     return do_cg_rows<N, EP_CROSS>(h, a, st);
 }
@@ -1195,11 +1285,35 @@ int cross_dev(ptycho_handle h, const double* gamma_dev, hipStream_t st, int s1_s
     PTY_DISPATCH(h->ge.ndet, (do_cross_dev<NN>(h, gamma_dev, st, s1_slot)));
 }
 
+int argmax_native(ptycho_handle h, int slot, unsigned long long* best, hipStream_t st) {   // best was cleared by the CROSS stage
+    PTY_DISPATCH(h->ge.ndet, (do_cg_argmax<NN>(h, slot, best, st, true)));
+}
+
 int check_stage(ptycho_handle h, const void* state) {
     int rc = check_handle(h);
     if (rc) return rc;
     if (!state) return fail(PTYCHO_ERR_ARG, "null state");
     return PTYCHO_OK;
+}
+
+// row stages of the native loop: sums are STORED by the stage's last workgroup (no zero fill of the state)
+int stats_native(ptycho_handle h, int slot, const void* data, double* sums, hipStream_t st) {
+    RowFusedArgs a{};
+    a.s1 = h->work[slot]; a.data = (const float*)data; a.sums = sums; a.overwrite = 1;
+    PTY_DISPATCH(h->ge.ndet, (do_cg_rows<NN, EP_STATS>(h, a, st)));
+}
+int project_native(ptycho_handle h, int src_slot, int dst_slot, const void* data, const double* ab, double* cost, hipStream_t st) {
+    int rc = ensure_work(h, dst_slot);
+    if (rc) return rc;
+    RowFusedArgs a{};
+    a.s1 = h->work[src_slot]; a.out = h->work[dst_slot]; a.data = (const float*)data; a.sums = cost; a.ab = ab; a.overwrite = 1;
+    rc = project_maxword(h, dst_slot, a, st);
+    if (rc) return rc;
+    h->slot_max_ok[dst_slot] = a.maxword != nullptr;
+    PTY_DISPATCH(h->ge.ndet, (do_cg_rows<NN, EP_PROJECT>(h, a, st)));
+}
+int adj_cols_native(ptycho_handle h, int slot, void* f, const void* scan, void* prb, int flg, const double* known_omax, int finish, hipStream_t st) {
+    PTY_DISPATCH(h->ge.ndet, (do_cg_adj_cols<NN>(h, slot, (c32*)f, (const float*)scan, (c32*)prb, flg, st, known_omax, finish)));
 }
 
 }  // namespace
@@ -1212,11 +1326,11 @@ int ptycho_cg_obj_begin(ptycho_handle h, double* state, const void* psi, const v
     if (rc) return rc;
     if (!psi || !scan || !prb || !data) return fail(PTYCHO_ERR_ARG, "null operand");
     hipStream_t st = (hipStream_t)stream;
-    h->trust_order = 1;   // the native loop keeps track of scan itself (ptycho_cg_obj_finish invalidates the order)
-    HIP_TRY(hipMemsetAsync(state, 0, PTYCHO_ST_ZEROED * sizeof(double), st));
+    h->native_order = 1;   // the native loop keeps track of scan itself (ptycho_cg_obj_finish invalidates the order)
+    h->det_pending = false;
     rc = ptycho_cg_fwd_cols(h, 0, psi, scan, prb, stream);
     if (rc) return rc;
-    return ptycho_cg_stats(h, 0, data, state + PTYCHO_ST_A, stream);
+    return stats_native(h, 0, data, state + PTYCHO_ST_A, st);
 }
 
 int ptycho_cg_obj_grad(ptycho_handle h, double* state, const void* scan, void* prb, const void* data, void* grad,
@@ -1227,11 +1341,16 @@ int ptycho_cg_obj_grad(ptycho_handle h, double* state, const void* scan, void* p
     hipStream_t st = (hipStream_t)stream;
     const Geom& ge = h->ge;
     const long long np = (long long)ge.ptheta * ge.nprb * ge.nprb, no = (long long)ge.ptheta * ge.nz * ge.n;
-    hipLaunchKernelGGL(k_cg_scale_probe, dim3(small_grid(h, np)), dim3(256), 0, st, (c32*)prb, np, (const double*)state);
-    rc = ptycho_cg_project(h, 0, 1, data, state + PTYCHO_ST_A, state + PTYCHO_ST_COST, stream);
+    // probe *= a / b (ptycho.py:344) and max |probe| (the gradient normalisation of :356 and the fixed-point scale) in one pass
+    hipLaunchKernelGGL(k_cg_absmax, dim3(fold_grid(h, np, 4)), dim3(256), 0, st, (c32*)prb, np, state + PTYCHO_ST_MAX_PRB,
+                       (double*)nullptr, (const double*)(state + PTYCHO_ST_A), h->fold);
+    h->max_prb_valid = true;
+    rc = project_native(h, 0, 1, data, state + PTYCHO_ST_A, state + PTYCHO_ST_COST, st);
     if (rc) return rc;
-    HIP_TRY(hipMemsetAsync(grad, 0, (size_t)no * sizeof(c32), st));
-    return ptycho_cg_adj_cols(h, 1, grad, scan, prb, 0, stream);
+    const bool window = h->use_window && h->ge.ndet <= 512;
+    const bool det = h->deterministic && window;
+    if (!det) HIP_TRY(hipMemsetAsync(grad, 0, (size_t)no * sizeof(c32), st));   // float atomics accumulate into grad
+    return adj_cols_native(h, 1, grad, scan, prb, 0, state + PTYCHO_ST_MAX_PRB, det ? (h->defer_finish ? -1 : 0) : 1, st);
 }
 
 int ptycho_cg_obj_dir(ptycho_handle h, double* state, int first, const void* scan, const void* prb, const void* data,
@@ -1242,15 +1361,19 @@ int ptycho_cg_obj_dir(ptycho_handle h, double* state, int first, const void* sca
     hipStream_t st = (hipStream_t)stream;
     const Geom& ge = h->ge;
     const long long np = (long long)ge.ptheta * ge.nprb * ge.nprb, no = (long long)ge.ptheta * ge.nz * ge.n;
-    hipLaunchKernelGGL(k_cg_absmax, dim3(small_grid(h, np)), dim3(256), 0, st, (const c32*)prb, np, state + PTYCHO_ST_MAX_PRB);
-    hipLaunchKernelGGL(k_cg_dy_reduce, dim3(small_grid(h, no)), dim3(256), 0, st, (c32*)grad, (const c32*)dpsi, (const c32*)grad0, no,
-                       (const double*)(state + PTYCHO_ST_MAX_PRB), 0.0f, 0.0f, state + PTYCHO_ST_DY_OBJ, first);
+    if (!h->max_prb_valid)
+        hipLaunchKernelGGL(k_cg_absmax, dim3(fold_grid(h, np, 4)), dim3(256), 0, st, (c32*)prb, np, state + PTYCHO_ST_MAX_PRB,
+                           (double*)nullptr, (const double*)nullptr, h->fold);
+    h->max_prb_valid = false;
+    hipLaunchKernelGGL(k_cg_dy_reduce, dim3(fold_grid(h, no, 4)), dim3(256), 0, st, (c32*)grad, (const c32*)dpsi, (const c32*)grad0, no,
+                       (const double*)(state + PTYCHO_ST_MAX_PRB), 0.0f, 0.0f, state + PTYCHO_ST_DY_OBJ, first,
+                       h->det_pending ? h->det_acc : (long long*)nullptr, h->last_det, h->fold);
+    h->det_pending = false;
     hipLaunchKernelGGL(k_cg_dy_update, dim3(small_grid(h, no)), dim3(256), 0, st, (c32*)dpsi, (c32*)grad0, (const c32*)grad, no,
-                       (const double*)(state + PTYCHO_ST_DY_OBJ), first);
+                       (const double*)(state + PTYCHO_ST_DY_OBJ), first, state, 0);
     rc = ptycho_cg_fwd_cols(h, 1, dpsi, scan, prb, stream);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_cg_ls_prepare, dim3(1), dim3(1), 0, st, state, 0);
-    return ls_pass(h, data, 1, state, st);
+    return ls_pass(h, data, 1, state, st, 0, h->ls_fused_decide ? kLsNext[1] : -1);
 }
 
 int ptycho_cg_ls_next(ptycho_handle h, double* state, int which, int pass, const void* data, int use_ab, void* stream) {
@@ -1258,15 +1381,17 @@ int ptycho_cg_ls_next(ptycho_handle h, double* state, int which, int pass, const
     if (rc) return rc;
     if (which < 0 || which > 1 || pass < 1 || pass > 7 || !data) return fail(PTYCHO_ERR_ARG, "bad line-search stage");
     hipStream_t st = (hipStream_t)stream;
-    // passes: <= 16 step lengths (sized from the last accepted index), then 16, 32, 64 more: 2^-106 < 1e-32 is covered.
-    // For callers that pay a collective per pass: 6 then 7 (32, then the 80 that are left), or 5 (all 112 at once).
-    static const int kNext[8] = {0, 1, 2, 4, 0, kLsGroupsMax, 2, 5};
-    const int next_groups = kNext[pass];
+    if (h->ls_fused_decide) {
+        // the pass before this call has decided on its own totals and sized this one: just issue it
+        if (pass > 3) return pass == 4 ? (int)PTYCHO_OK : fail(PTYCHO_ERR_ARG, "option ls_fused_decide: passes 1, 2, 3, 4 only");
+        return ls_pass(h, data, use_ab, state, st, which, kLsNext[pass + 1]);
+    }
+    const int next_groups = kLsNext[pass];
     hipLaunchKernelGGL(k_cg_ls_decide, dim3(1), dim3(1), 0, st, state, which,
                        which == 0 ? (int)PTYCHO_ST_GAMMA_PSI : (int)PTYCHO_ST_GAMMA_PRB, next_groups);
     HIP_TRY(hipGetLastError());
     if (pass == 4) return PTYCHO_OK;
-    return ls_pass(h, data, use_ab, state, st);
+    return ls_pass(h, data, use_ab, state, st, which, -1);
 }
 
 int ptycho_cg_obj_finish(ptycho_handle h, double* state, int correct_positions, void* psi, const void* dpsi, void* scan,
@@ -1297,12 +1422,11 @@ int ptycho_cg_obj_finish(ptycho_handle h, double* state, int correct_positions, 
         if (rc) return rc;
         rc = cross_dev(h, state + PTYCHO_ST_GAMMA_PSI, st, s1);
         if (rc) return rc;
-        rc = ptycho_cg_argmax(h, 1, h->reg_best, stream);
+        rc = argmax_native(h, 1, h->reg_best, st);
         if (rc) return rc;
-        rc = ptycho_cg_zoom(h, h->reg_ip, h->reg_best, vt, lz, nc, ups, upsample_factor, h->reg_shifts, stream);
+        // the kernel that finds the shifts also adds them to scan[0, :] (ptycho.py:403)
+        rc = zoom_impl(h, h->reg_ip, h->reg_best, vt, lz, nc, ups, upsample_factor, h->reg_shifts, (float*)scan, stream);
         if (rc) return rc;
-        hipLaunchKernelGGL(k_cg_add_shifts, dim3((unsigned)((2 * npos + 255) / 256)), dim3(256), 0, st, (float*)scan,
-                           (const double*)h->reg_shifts, (int)(2 * npos));
         h->order_scan = nullptr;   // the positions moved: the next column pass sorts again
     }
     hipLaunchKernelGGL(k_cg_axpy, dim3(small_grid(h, no)), dim3(256), 0, st, (c32*)psi, (const c32*)dpsi, no,
@@ -1326,13 +1450,19 @@ int ptycho_cg_prb_grad(ptycho_handle h, double* state, const void* psi, const vo
     if (!psi || !scan || !prb || !data || !gprb) return fail(PTYCHO_ERR_ARG, "null operand");
     hipStream_t st = (hipStream_t)stream;
     const Geom& ge = h->ge;
-    const long long np = (long long)ge.ptheta * ge.nprb * ge.nprb;
+    const long long np = (long long)ge.ptheta * ge.nprb * ge.nprb, no = (long long)ge.ptheta * ge.nz * ge.n;
     rc = ptycho_cg_fwd_cols(h, 0, psi, scan, prb, stream);
     if (rc) return rc;
-    rc = ptycho_cg_project(h, 0, 1, data, nullptr, state + PTYCHO_ST_COST2, stream);
+    // max |psi|: the gradient normalisation of ptycho.py:431 and the fixed-point scale of the probe adjoint
+    hipLaunchKernelGGL(k_cg_absmax, dim3(fold_grid(h, no, 4)), dim3(256), 0, st, (c32*)psi, no, state + PTYCHO_ST_MAX_PSI,
+                       (double*)nullptr, (const double*)nullptr, h->fold);
+    h->max_psi_valid = true;
+    rc = project_native(h, 0, 1, data, nullptr, state + PTYCHO_ST_COST2, st);
     if (rc) return rc;
-    HIP_TRY(hipMemsetAsync(gprb, 0, (size_t)np * sizeof(c32), st));
-    return ptycho_cg_adj_cols(h, 1, (void*)psi, scan, gprb, 1, stream);
+    const bool window = h->use_window && h->ge.ndet <= 512;
+    const bool det = h->deterministic && window;
+    if (!det) HIP_TRY(hipMemsetAsync(gprb, 0, (size_t)np * sizeof(c32), st));
+    return adj_cols_native(h, 1, (void*)psi, scan, gprb, 1, state + PTYCHO_ST_MAX_PSI, det ? (h->defer_finish ? -1 : 0) : 1, st);
 }
 
 int ptycho_cg_prb_dir(ptycho_handle h, double* state, int first, double nscan_total, double nmodes, const void* psi,
@@ -1343,15 +1473,19 @@ int ptycho_cg_prb_dir(ptycho_handle h, double* state, int first, double nscan_to
     hipStream_t st = (hipStream_t)stream;
     const Geom& ge = h->ge;
     const long long np = (long long)ge.ptheta * ge.nprb * ge.nprb, no = (long long)ge.ptheta * ge.nz * ge.n;
-    hipLaunchKernelGGL(k_cg_absmax, dim3(small_grid(h, no)), dim3(256), 0, st, (const c32*)psi, no, state + PTYCHO_ST_MAX_PSI);
-    hipLaunchKernelGGL(k_cg_dy_reduce, dim3(small_grid(h, np)), dim3(256), 0, st, (c32*)gprb, (const c32*)dprb, (const c32*)gprb0, np,
-                       (const double*)(state + PTYCHO_ST_MAX_PSI), (float)nscan_total, (float)nmodes, state + PTYCHO_ST_DY_PRB, first);
+    if (!h->max_psi_valid)
+        hipLaunchKernelGGL(k_cg_absmax, dim3(fold_grid(h, no, 4)), dim3(256), 0, st, (c32*)psi, no, state + PTYCHO_ST_MAX_PSI,
+                           (double*)nullptr, (const double*)nullptr, h->fold);
+    h->max_psi_valid = false;
+    hipLaunchKernelGGL(k_cg_dy_reduce, dim3(fold_grid(h, np, 4)), dim3(256), 0, st, (c32*)gprb, (const c32*)dprb, (const c32*)gprb0, np,
+                       (const double*)(state + PTYCHO_ST_MAX_PSI), (float)nscan_total, (float)nmodes, state + PTYCHO_ST_DY_PRB, first,
+                       h->det_pending ? h->det_acc : (long long*)nullptr, h->last_det, h->fold);
+    h->det_pending = false;
     hipLaunchKernelGGL(k_cg_dy_update, dim3(small_grid(h, np)), dim3(256), 0, st, (c32*)dprb, (c32*)gprb0, (const c32*)gprb, np,
-                       (const double*)(state + PTYCHO_ST_DY_PRB), first);
+                       (const double*)(state + PTYCHO_ST_DY_PRB), first, state, 1);
     rc = ptycho_cg_fwd_cols(h, 1, psi, scan, dprb, stream);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_cg_ls_prepare, dim3(1), dim3(1), 0, st, state, 1);
-    return ls_pass(h, data, 0, state, st);
+    return ls_pass(h, data, 0, state, st, 1, h->ls_fused_decide ? kLsNext[1] : -1);
 }
 
 int ptycho_cg_prb_finish(ptycho_handle h, double* state, void* prb, const void* dprb, void* stream) {

@@ -714,6 +714,12 @@ class CGPtychoSolver(PtychoHIP):
         nscan_total = float(self._nscan_total())
         dist_on = self.group is not None
         two_pass = dist_on if self.ls_two_pass is None else self.ls_two_pass
+        # one GPU: nothing is all-reduced between the stages, so a line-search pass decides on its own totals (no
+        # decision kernel in between) and the gradient goes from the adjoint's fixed-point image straight into the
+        # Dai-Yuan pass (no fold-in pass of its own); with a process group the stages stay separate
+        single = not dist_on and not two_pass
+        nat.check(nat.set_option(h, b"ls_fused_decide", int(single)))
+        nat.check(nat.set_option(h, b"defer_finish", int(not dist_on)))
 
         def line_search(which, use_ab, S):
             # one GPU: 16 + 32 + 64 more step lengths in passes that return at once when resolved; with a
@@ -721,7 +727,7 @@ class CGPtychoSolver(PtychoHIP):
             # would save one more collective, but a search that ends at index 30-50 -- a quarter of the bench
             # problem's iterations -- would then price 112 step lengths instead of 32: +2 ms per iteration at 4096
             # positions; ls_two_pass = "all" selects it)
-            for p in ((5, 4) if two_pass == "all" else (6, 7, 4) if two_pass else (1, 2, 3, 4)):
+            for p in ((5, 4) if two_pass == "all" else (6, 7, 4) if two_pass else (1, 2, 3) if single else (1, 2, 3, 4)):
                 if dist_on:
                     self._allreduce(costs)
                 nat.check(nat.cg_ls_next(h, sp, which, p, _ptr(data), use_ab, S))
@@ -778,6 +784,8 @@ class CGPtychoSolver(PtychoHIP):
             self._scan_key = None
             self._scan_trusted = None
             nat.check(nat.set_option(self._h, b"trust_order", 0))
+            nat.check(nat.set_option(self._h, b"ls_fused_decide", 0))
+            nat.check(nat.set_option(self._h, b"defer_finish", 0))
         failed = int(st[nat.ST_LS_FAILED].item())
         if failed:
             st[nat.ST_LS_FAILED] = 0.0
