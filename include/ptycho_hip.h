@@ -26,7 +26,8 @@
  *   g    farplane complex64 [ptheta][nscan][ndet][ndet]   (DC at [0][0])
  *   prb  probe    complex64 [ptheta][nprb][nprb]
  *   scan          float32   [ptheta][nscan][2]  ([..][0] = row/y, [..][1] = column/x)
- * ndet must be a power of two in [16, 2048]; nprb <= ndet.
+ * ndet: 2 .. 1024, or a power of two up to 2048 (powers of two >= 16 run the fused Stockham kernels, every other
+ * size a Bluestein transform on the next power-of-two plan); nprb <= ndet.
  */
 #ifndef PTYCHO_HIP_H
 #define PTYCHO_HIP_H
@@ -79,7 +80,8 @@ int ptycho_fft2(ptycho_handle h, void* dst, const void* src, size_t nbatch,
  * single-mode loop uses 0 and 1, the multi-mode loop one pair (2k, 2k+1) per probe mode)
  * that hold column-pass intermediates between calls.  sums/cost/costs and ab are DEVICE
  * pointers to float64 (ab = {a, b} of ptycho.py:342-343; NULL means scale 1); the
- * kernels ADD into sums/cost/costs, the caller zeroes them.
+ * kernels ADD into sums/cost/costs, the caller zeroes them.  Every such sum is formed in a fixed order (per-workgroup
+ * partials, folded by the last workgroup to finish): the same inputs give the same bits, whatever the scheduling.
  *   ptycho_cg_fwd_cols   slot <- column pass of fwd(f, scan, prb)            (ptycho.py:332)
  *   ptycho_cg_stats      sums += { sum sqrt(|g|^2 d), sum |g|^2 }            (ptycho.py:333,342-343)
  *   ptycho_cg_project    dst  <- IDFT_x( fpsi - sqrt(d) fpsi / (sqrt(I)+1e-32) ), cost += ||sqrt I - sqrt d||^2
@@ -170,13 +172,19 @@ int ptycho_cg_zoom(ptycho_handle h, const void* image_product, const void* best,
  * stages a multi-GPU caller all-reduces (sum) the words / arrays named below; a single-GPU caller
  * just calls them back to back.  One probe mode, gaussian model, ptheta = 1 for the position step.
  *
- *   ptycho_cg_obj_begin   state[A,B,COST..] <- 0; slot 0 <- column pass of fwd(psi, probe); state[A,B] += statistics
- *                         (ptycho.py:330-343).                       all-reduce: state[PTYCHO_ST_A .. +2)
- *   ptycho_cg_obj_grad    probe *= a/b (:344); slot 1 <- projected residual, state[COST] += cost (:347-353);
- *                         grad <- adj (raw, not yet divided by max|probe|^2).   all-reduce: grad
+ *   ptycho_cg_obj_begin   slot 0 <- column pass of fwd(psi, probe); state[A,B] <- statistics (stored, like every sum of
+ *                         the native stages: the state needs no zero fill) (ptycho.py:330-343).
+ *                                                                    all-reduce: state[PTYCHO_ST_A .. +2)
+ *   ptycho_cg_obj_grad    probe *= a/b (:344) and state[MAX_PRB] <- max|probe| in one pass; slot 1 <- projected residual,
+ *                         state[COST] <- cost (:347-353); grad <- adj (raw, not yet divided by max|probe|^2; stored, no
+ *                         zero fill needed with the deterministic adjoints).   all-reduce: grad
+ *                         Option "defer_finish" (single GPU): grad stays in the adjoint's fixed-point image and
+ *                         ptycho_cg_obj_dir folds it in -- do not read grad between the two calls.
  *   ptycho_cg_obj_dir     grad /= max|probe|^2 (:356); Dai-Yuan dpsi, grad0 <- grad (:366-373); slot 1 <- column
  *                         pass of fwd(dpsi, probe); first line-search pass (:383-393).
  *                                                                    all-reduce: state[PTYCHO_ST_COSTS .. +119)
+ *                         Option "ls_fused_decide" (single GPU): every pass replays line_search_sqr on its own totals
+ *                         in its last workgroup; ptycho_cg_ls_next(pass = 1, 2, 3) then only issues the next pass.
  *   ptycho_cg_ls_next     decide on the pass just reduced (line_search_sqr, :253-281); pass = 1, 2, 3: issue the next
  *                         pass (16, 32, 64 step lengths; each returns at once when the search is already
  *                         resolved) -> all-reduce state[COSTS..] again; pass = 4: decide only.  For a multi-GPU
@@ -186,7 +194,8 @@ int ptycho_cg_zoom(ptycho_handle h, const void* image_product, const void* best,
  *   ptycho_cg_reg_prepare (optional, multi-GPU) slot 2 <- column pass of fwd(psi, ones): the first operand of the position
  *                         correction depends on psi and scan only, so a caller that has to wait for the gradient
  *                         all-reduce anyway issues it in that gap; ptycho_cg_obj_finish then takes correct_positions = 2
- *   ptycho_cg_obj_finish  i > 0: position correction (:398-403; needs the zoom factors of ptycho_cg_zoom), scan[0] += shifts;
+ *   ptycho_cg_obj_finish  i > 0: position correction (:398-403; needs the zoom factors of ptycho_cg_zoom), scan[0] += shifts
+ *                         (by the kernel that finds them; the next column pass re-sorts the positions);
  *                         psi += gamma dpsi (:405).  correct_positions: 0 off, 1 on, 2 on with slot 2 prepared
  *   ptycho_cg_prb_grad    slot 0 <- column pass of fwd(psi, probe); slot 1 <- projected residual (:421-430);
  *                         gprb <- adj_probe (raw).                   all-reduce: gprb
@@ -199,7 +208,7 @@ enum {
     PTYCHO_ST_COST = 2, PTYCHO_ST_COST2 = 3,    /* start-of-iteration cost; probe-step scratch */
     PTYCHO_ST_DY_OBJ = 4, PTYCHO_ST_DY_PRB = 7, /* 3 words each: ||g||^2, Re, Im sum conj(d)(g - g0) */
     PTYCHO_ST_MAX_PRB = 10, PTYCHO_ST_MAX_PSI = 11,   /* float bits of max|.| in the low half of the word */
-    PTYCHO_ST_ZEROED = 12,                      /* words [0, 12) are cleared by ptycho_cg_obj_begin */
+    PTYCHO_ST_ZEROED = 12,                      /* (rounds 1-2: words [0, 12) were cleared by ptycho_cg_obj_begin; now every sum is stored) */
     PTYCHO_ST_GAMMA_PSI = 12, PTYCHO_ST_GAMMA_PRB = 13,
     PTYCHO_ST_LS_GAMMA0 = 14, PTYCHO_ST_LS_NCAND = 15, PTYCHO_ST_LS_NGROUPS = 16, PTYCHO_ST_LS_TRIED = 17,
     PTYCHO_ST_LS_RESOLVED = 18, PTYCHO_ST_LS_FAILED = 19,
@@ -235,20 +244,22 @@ int ptycho_cg_prb_finish(ptycho_handle h, double* state, void* prb, const void* 
  * g for the scale (none after ptycho_cg_project, which leaves max |slot| on the device); needs the windowed kernels,
  * ndet <= 512; default 0: float atomics, as kernels.cu:73-80,92-93);
  * "compact_modes" (M = number of probe modes: compact slot layout + chunk-major position order, see above; 0 = slot pairs);
- * "fused" (ndet = 256: forward operator as ONE launch that keeps the column<->row intermediate on
- * the CU, k_fwd_fused256: 0 = off, 1 / 2 = one / two class tiles per pass).
- * Environment variables read at handle creation / first launch, for experiments only:
- * PTYCHO_HIP_CHUNK, PTYCHO_HIP_WINDOW, PTYCHO_HIP_SPLIT, PTYCHO_HIP_FUSED (initial values of the
- * options above), PTYCHO_HIP_NT (nontemporal load/store mask), PTYCHO_HIP_ROWGRID, PTYCHO_HIP_COLSEGS (launch
- * geometry), PTYCHO_HIP_ZOOM_SCALAR (zoomed DFT without the matrix cores). */
+ * "defer_finish", "ls_fused_decide" (native CG stages on one GPU, see above; default 0);
+ * "trust_order" is the CALLER's: the native CG stages track the scan buffer themselves and do not touch it.
+ * Experiments build only (make experiments, -DPTYCHO_EXPERIMENTS; the shipped library rejects / ignores them):
+ * "fused" (ndet = 256: forward operator as ONE launch that keeps the column<->row intermediate on the CU,
+ * k_fwd_fused256: 0 = off, 1 / 2 = one / two class tiles per pass; measured slower) and the
+ * environment variables PTYCHO_HIP_CHUNK, PTYCHO_HIP_WINDOW, PTYCHO_HIP_SPLIT, PTYCHO_HIP_FUSED (initial values
+ * of the options above), PTYCHO_HIP_NT (nontemporal load/store mask), PTYCHO_HIP_ROWGRID, PTYCHO_HIP_COLSEGS,
+ * PTYCHO_HIP_MINSEG (launch geometry), PTYCHO_HIP_NMMAX, PTYCHO_HIP_ZOOM_SCALAR (zoomed DFT without the matrix cores). */
 int ptycho_set_option(ptycho_handle h, const char* name, long long value);
 
 /* In-library profiler for bench.py: when enabled, every kernel launch is
  * bracketed by HIP events on the caller's stream.  ptycho_profile_read waits for
  * the recorded launches, returns summed milliseconds and launch counts per kernel
  * (index 0 k_cols<FWD>, 1 k_rows<fwd>, 2 k_rows<inv>, 3 k_cols<ADJ_OBJ>,
- * 4 k_cols<ADJ_PRB>, 5 k_cols<PLAIN>, 6 position sort, 7-9 fused CG row passes,
- * 10 k_fwd_team, 11-12 unused, 13 cross row pass,
+ * 4 k_cols<ADJ_PRB>, 5 k_cols<PLAIN>, 6 position sort, 7 / 8 / 9 fused CG row passes (statistics / projection /
+ * line search), 10 unused, 11 single-launch forward (experiments build), 12 unused, 13 cross row pass,
  * 14 arg-max column pass, 15 zoomed DFT + arg-max; n >= 16)
  * and clears the record.
  * No counterpart in the reference (it has no timing code). */

@@ -13,7 +13,7 @@
 // writes y[(j/Ns)*Ns*R + (j mod Ns) + t'*Ns].
 //
 // The header is plain C++ (clang vector extensions) so the index arithmetic can
-// be exercised on the host: tests/test_fft_core_host.py builds csrc/host_check.cpp
+// be exercised on the host: tests/test_native_cpu.py::test_fft_core_on_host builds csrc/host_check.cpp
 // with clang++ and compares against numpy.fft.  On the device every loop below is
 // fully unrolled and every array lives in VGPRs.
 #pragma once

@@ -1,7 +1,7 @@
 // Host-side check of fft_core.hpp: emulates the T cooperating threads of every
 // plan sequentially (one "phase" per Stockham step, a barrier between phases)
 // and compares with a naive double-precision DFT.  Built by
-// tests/test_fft_core_host.py with clang++ (no GPU involved).
+// tests/test_native_cpu.py::test_fft_core_on_host with clang++ (no GPU involved).
 #include <cmath>
 #include <complex>
 #include <cstdio>

@@ -40,7 +40,9 @@ namespace {
 #include "k_cols_plain.hpp"
 #include "k_rows.hpp"
 #include "k_cols_window.hpp"
-#include "k_fwd_fused.hpp"
+#ifdef PTYCHO_EXPERIMENTS
+#include "k_fwd_fused.hpp"   // single-launch forward: measured slower, experiments build only
+#endif
 #include "k_cg_small.hpp"
 #include "k_generic.hpp"
 #include "k_zoom.hpp"
@@ -49,6 +51,17 @@ namespace {
 // host side
 // ---------------------------------------------------------------------------
 thread_local std::string g_err;
+
+// Launch-geometry and code-path knobs read from the environment exist only in the experiments build
+// (`make -C libtike-cufft_amd/csrc experiments`, -DPTYCHO_EXPERIMENTS); the shipped library uses the defaults.
+#ifdef PTYCHO_EXPERIMENTS
+int exp_env(const char* name, int dflt) {
+    const char* e = std::getenv(name);
+    return e ? std::atoi(e) : dflt;
+}
+#else
+constexpr int exp_env(const char*, int dflt) { return dflt; }
+#endif
 
 // kernel ids for the in-library profiler (ptycho_profile_read)
 enum { K_COLS_FWD = 0, K_ROWS_FWD = 1, K_ROWS_INV = 2, K_COLS_ADJ_OBJ = 3, K_COLS_ADJ_PRB = 4, K_COLS_PLAIN = 5, K_SORT = 6, K_ROWS_STATS = 7, K_ROWS_PROJECT = 8, K_ROWS_LINESEARCH = 9, K_CG_SCALARS = 10, K_FWD_FUSED = 11, K_CG_UPDATE = 12, K_ROWS_CROSS = 13, K_COLS_ARGMAX = 14, K_ZOOM = 15, K_COUNT = 16 };
@@ -136,8 +149,7 @@ struct ProfSpan {   // brackets one launch with events when profiling is on
 };
 
 long long default_chunk(const Geom& ge) {
-    const char* env = std::getenv("PTYCHO_HIP_CHUNK");
-    if (env && std::atoll(env) > 0) return std::atoll(env);
+    if (exp_env("PTYCHO_HIP_CHUNK", 0) > 0) return exp_env("PTYCHO_HIP_CHUNK", 0);
     // Large chunks stream best (measured: the row pass runs at ~5-6 TB/s for chunks
     // >= 256 MiB; small chunks only add launch gaps).  Cap the scratch at 4 GiB.
     const long long per = (long long)ge.ndet * ge.ndet * 8;
@@ -161,7 +173,7 @@ int alloc_scratch(ptycho_handle h) {
 int sort_positions(ptycho_handle h, const float* scan, hipStream_t st);   // ptycho_sort.hip-style helper below
 
 // shortest run of sorted positions a windowed column workgroup takes (each run pays one window fill)
-static int min_seglen() { static const int v = std::getenv("PTYCHO_HIP_MINSEG") ? std::atoi(std::getenv("PTYCHO_HIP_MINSEG")) : 16; return v < 1 ? 1 : v; }   // 512 positions x 256^2 CG: 8 -> 1.44, 16 -> 1.36, 24 -> 1.51 ms per iteration
+static int min_seglen() { static const int v = exp_env("PTYCHO_HIP_MINSEG", 16); return v < 1 ? 1 : v; }   // 512 positions x 256^2 CG: 8 -> 1.44, 16 -> 1.36, 24 -> 1.51 ms per iteration
 
 template <int N, int DIR, int MODE>
 int launch_cols(ptycho_handle h, ColArgs a, hipStream_t st) {
@@ -195,7 +207,7 @@ int launch_adjwin(ptycho_handle h, ColArgs a, hipStream_t st, int wg_target = 0)
     if (seglen < min_seglen()) seglen = min_seglen();
     if (seglen > kRunMax) seglen = kRunMax;
     nseg = (np + seglen - 1) / seglen;
-    static const int nt_mode_a = std::getenv("PTYCHO_HIP_NT") ? std::atoi(std::getenv("PTYCHO_HIP_NT")) : 0;
+    static const int nt_mode_a = exp_env("PTYCHO_HIP_NT", 0);
     a.nt = nt_mode_a;
 #ifdef PTY_STAMPS
     a.stamps = h->stamps;
@@ -220,15 +232,17 @@ int launch_gatherwin(ptycho_handle h, ColArgs a, hipStream_t st, int wg_target =
     if (seglen < min_seglen()) seglen = min_seglen();
     if (seglen > kRunMax) seglen = kRunMax;
     nseg = (np + seglen - 1) / seglen;
-    if (const char* e = std::getenv("PTYCHO_HIP_COLSEGS")) {   // experiment knob: fewer, longer runs
-        const int want = std::atoi(e);
+#ifdef PTYCHO_EXPERIMENTS
+    {   // experiment knob: fewer, longer runs
+        const int want = exp_env("PTYCHO_HIP_COLSEGS", 0);
         if (want > 0) {
             seglen = (np + want - 1) / want;
             if (seglen > kRunMax) seglen = kRunMax;
             nseg = (np + seglen - 1) / seglen;
         }
     }
-    static const int nt_mode_g = std::getenv("PTYCHO_HIP_NT") ? std::atoi(std::getenv("PTYCHO_HIP_NT")) : 0;
+#endif
+    static const int nt_mode_g = exp_env("PTYCHO_HIP_NT", 0);
     a.nt = nt_mode_g;
 #ifdef PTY_STAMPS
     a.stamps = h->stamps;
@@ -249,7 +263,7 @@ int launch_rows(ptycho_handle h, RowArgs a, hipStream_t st) {
     long long grid = nb < (long long)h->n_cu * 8 ? nb : (long long)h->n_cu * 8;
     // nontemporal row-pass loads and stores: the rows are streamed once (measured 3-4 % on the pair;
     // nontemporal column-pass accesses made no difference).  PTYCHO_HIP_NT overrides (bit mask).
-    static const int nt_mode = std::getenv("PTYCHO_HIP_NT") ? std::atoi(std::getenv("PTYCHO_HIP_NT")) : 3;
+    static const int nt_mode = exp_env("PTYCHO_HIP_NT", 3);
     a.nt = nt_mode;
     {
         ProfSpan ps(h, DIR < 0 ? K_ROWS_FWD : K_ROWS_INV, st);
@@ -265,7 +279,7 @@ int launch_rows_split(ptycho_handle h, RowArgs a, hipStream_t st) {
     const long long nitems = (a.nrows / N) * 16;
     // measured at 4096 x 256^2: forward best with ~32 workgroups per CU in the grid (0.73 ms vs 0.75
     // at 8), adjoint best with one item per workgroup (0.70 ms vs 0.78); PTYCHO_HIP_ROWGRID overrides
-    static const int env_mult = std::getenv("PTYCHO_HIP_ROWGRID") ? std::atoi(std::getenv("PTYCHO_HIP_ROWGRID")) : 0;
+    static const int env_mult = exp_env("PTYCHO_HIP_ROWGRID", 0);
     const int mult = env_mult > 0 ? env_mult : (DIR < 0 ? 32 : 256);
     long long grid = nitems < (long long)h->n_cu * mult ? nitems : (long long)h->n_cu * mult;
     {
@@ -285,6 +299,7 @@ void strip_range(const Geom& ge, int& strip0, int& nstrips) {
 }
 
 
+#ifdef PTYCHO_EXPERIMENTS
 int do_fwd_fused(ptycho_handle h, c32* g, const c32* f, const float* scan, const c32* prb, hipStream_t st) {
     const Geom& ge = h->ge;
     const int total = ge.ptheta * ge.nscan;
@@ -308,6 +323,7 @@ int do_fwd_fused(ptycho_handle h, c32* g, const c32* f, const float* scan, const
     HIP_TRY(hipGetLastError());
     return PTYCHO_OK;
 }
+#endif
 
 template <int N>
 int do_fwd(ptycho_handle h, c32* g, const c32* f, const float* scan, const c32* prb, hipStream_t st) {
@@ -318,10 +334,12 @@ int do_fwd(ptycho_handle h, c32* g, const c32* f, const float* scan, const c32* 
     strip_range<N>(ge, strip0, nstrips);
     const bool window = h->use_window && WinCfg<N>::fits;
     int rc = PTYCHO_OK;
+#ifdef PTYCHO_EXPERIMENTS
     if constexpr (N == 256) {
         // single launch, no intermediate in HBM; needs 16-byte aligned object rows
         if (h->use_fused && ge.n % 2 == 0 && ((size_t)f % 16) == 0) return do_fwd_fused(h, g, f, scan, prb, st);
     }
+#endif
     if (window) {
         rc = sort_positions(h, scan, st);
         if (rc) return rc;
@@ -828,12 +846,9 @@ int ptycho_create(ptycho_handle* out, size_t ptheta, size_t nz, size_t n, size_t
         delete h;
         return fail(PTYCHO_ERR_HIP, std::string("twiddle table: ") + hipGetErrorString(e));
     }
-    const char* env = std::getenv("PTYCHO_HIP_WINDOW");
-    if (env) h->use_window = std::atoi(env) != 0;
-    env = std::getenv("PTYCHO_HIP_SPLIT");
-    if (env) h->use_split = std::atoi(env) != 0;
-    env = std::getenv("PTYCHO_HIP_FUSED");
-    if (env) h->use_fused = std::atoi(env);
+    h->use_window = exp_env("PTYCHO_HIP_WINDOW", 1) != 0;
+    h->use_split = exp_env("PTYCHO_HIP_SPLIT", 1) != 0;
+    h->use_fused = exp_env("PTYCHO_HIP_FUSED", 0);
 
     h->chunk = default_chunk(h->ge);
     h->fold_rows = h->n_cu * 8 > 2048 ? h->n_cu * 8 : 2048;
@@ -923,8 +938,13 @@ int ptycho_set_option(ptycho_handle h, const char* name, long long value) {
         return PTYCHO_OK;
     }
     if (std::strcmp(name, "fused") == 0) {
+#ifdef PTYCHO_EXPERIMENTS
         h->use_fused = (int)value;
         return PTYCHO_OK;
+#else
+        if (value == 0) return PTYCHO_OK;
+        return fail(PTYCHO_ERR_ARG, "option fused: the single-launch forward is an experiment (measured slower, DESIGN.md); build with -DPTYCHO_EXPERIMENTS");
+#endif
     }
     if (std::strcmp(name, "defer_finish") == 0) {
         h->defer_finish = value != 0;
@@ -1210,7 +1230,7 @@ int zoom_impl(ptycho_handle h, const void* image_product, const void* best, cons
         const double *pv = (const double*)vt, *pl = (const double*)lz;
         hipLaunchKernelGGL(k_zoom_prepare, dim3((unsigned)npos), dim3(N < 256 ? N : 256), 0, st,
                            (const unsigned long long*)best, N, ups, upsample_factor, ppx, ppy, coarse);
-        static const bool no_mfma = std::getenv("PTYCHO_HIP_ZOOM_SCALAR") != nullptr;   // comparison knob
+        static const bool no_mfma = exp_env("PTYCHO_HIP_ZOOM_SCALAR", 0) != 0;   // comparison knob
         int* none = nullptr;
         if (N % 64 == 0 && !no_mfma) {
             if (N <= 256)
@@ -1537,7 +1557,7 @@ int do_cg_fwd_cols_modes(ptycho_handle h, int nmodes, c32* const* dst, const c32
     ColArgs ca{};
     ca.src = f; ca.scan = scan; ca.table = h->table; ca.ge = ge; ca.order = h->order;
     ca.k_begin = k_begin; ca.k_end = k_end; ca.strip0 = strip0; ca.nstrips = nstrips;
-    static const int nm_max = std::getenv("PTYCHO_HIP_NMMAX") ? std::atoi(std::getenv("PTYCHO_HIP_NMMAX")) : 4;   // comparison knob
+    static const int nm_max = exp_env("PTYCHO_HIP_NMMAX", 4);   // comparison knob
     int k = 0;
     while (k < nmodes) {
         const int left = nmodes - k;

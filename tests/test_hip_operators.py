@@ -184,45 +184,19 @@ def test_edge_cases(pt, case):
 
 
 def test_optional_paths_give_the_same_results(pt):
-    """ndet = 256 has three forward paths -- split two-pass (default), unsplit two-pass, and the
-    single-launch k_fwd_fused256 with one or two class tiles per pass -- and two adjoint paths;
-    all must agree."""
+    """ndet = 256 has two forward and two adjoint paths -- split two-pass (default) and unsplit two-pass; they must
+    agree.  (The single-launch forward of the experiments build: tests/test_hip_experiments.py.)"""
     p = syn.make_problem(48, 48, 4, 256, 256, seed=2, nz=512, n=512)          # 2304 positions
     rng = np.random.default_rng(1)
     y = (rng.standard_normal((1, 2304, 256, 256)) + 1j * rng.standard_normal((1, 2304, 256, 256))).astype(np.complex64)
     with pt.PtychoCuFFT(2304, 256, 256, 1, 512, 512) as slv:
         psi, scan, prb, yd = dev(p["psi"]), dev(p["scan"]), dev(p["probe"]), dev(y)
-        slv.set_fused(0)
         ref = [host(slv.fwd(psi, scan, prb)), host(slv.adj(yd, scan, prb)), host(slv.adj_probe(yd, scan, psi))]
         slv.set_split(False)               # unsplit column / row kernels
         uns = [host(slv.fwd(psi, scan, prb)), host(slv.adj(yd, scan, prb)), host(slv.adj_probe(yd, scan, psi))]
         slv.set_split(True)
         for a, b in zip(uns, ref):
             assert np.abs(a - b).max() <= 1e-5 * np.abs(b).max()
-        for tiles in (1, 2):
-            slv.set_fused(tiles)
-            one = host(slv.fwd(psi, scan, prb))
-            assert np.abs(one - ref[0]).max() <= 1e-5 * np.abs(ref[0]).max(), tiles
-
-
-@pytest.mark.parametrize("nprb,ntheta", [(256, 1), (128, 2), (200, 1)])
-def test_fused_forward_matches_oracle(pt, nprb, ntheta):
-    """k_fwd_fused256 (4 x 64 split of the DFT over y, tile in LDS) against the oracle: padded
-    probes, two angles, a skipped position and positions that overhang the object edges."""
-    p = syn.make_problem(3, 4, 13, nprb, 256, ntheta=ntheta, seed=3)
-    scan = p["scan"].copy()
-    scan[0, 0] = (-1.5, 3.0)                                # skipped (kernels.cu:39)
-    scan[0, 1] = (p["nz"] - nprb + 0.5, 2.25)               # overhangs the bottom edge
-    scan[0, 2] = (0.75, p["n"] - nprb - 0.5)                # touches the right edge
-    rng = np.random.default_rng(5)
-    prb = (p["probe"] * np.exp(2j * np.pi * rng.random((nprb, nprb)))).astype(np.complex64)
-    want = op.fwd(p["psi"], scan, prb, 256, "double")
-    with pt.PtychoCuFFT(p["nscan"], nprb, 256, ntheta, p["nz"], p["n"]) as slv:
-        for tiles in (1, 2):
-            slv.set_fused(tiles)
-            g = host(slv.fwd(dev(p["psi"]), dev(scan), dev(prb)))
-            assert np.abs(g - want).max() <= REL_MAX * np.abs(want).max(), tiles
-            assert not g[0, 0].any()
 
 
 def test_fft2_matches_numpy(pt):
