@@ -106,25 +106,67 @@ def cfg3_figures(pt, syn, dev, iters):
 
 
 def cpu_baseline(args, prob):
-    """fwd+adj patterns/s of the oracle (NumPy + scipy.fft on all host cores) on the
-    first ``--cpu-sample`` positions of the same workload."""
+    """The reference ships no CPU path (``array_module = cp`` only), so the CPU figures are the oracle's
+    (SURVEY.md 8d), timed on this host: (1) fwd+adj patterns/s with scipy.fft on all cores -- ``value`` --,
+    (2) the same with single-threaded numpy.fft, (3) CG iterations/s of the oracle loop on the first 8 x 8
+    positions of the workload, extrapolated linearly in the number of positions to the full batch."""
+    import warnings
     import scipy.fft
     from oracle import ptycho_oracle as op
+    from oracle import cg_oracle as cgo
     cores = len(os.sched_getaffinity(0))
     ns = min(args.cpu_sample, prob["scan"].shape[1])
     scan = prob["scan"][:, :ns]
     done, t_used = 0, 0.0
     with scipy.fft.set_workers(cores):
-        while t_used < 12.0:
+        while t_used < 10.0:
             t0 = time.perf_counter()
             g = op.fwd(prob["psi"], scan, prob["probe"], args.ndet)
             op.adj(g, scan, prob["probe"], prob["nz"], prob["n"])
             t_used += time.perf_counter() - t0
             done += ns
-    return {"value": done / t_used, "unit": "patterns/s", "cores": cores, "kind": "port",
-            "sample": "%d fwd+adj passes over the first %d positions of the workload "
-                      "(oracle/ptycho_oracle.py, complex64, scipy.fft workers=%d), %.1f s"
-                      % (done // ns, ns, cores, t_used)}
+    out = {"value": done / t_used, "unit": "patterns/s", "cores": cores, "kind": "port",
+           "sample": "%d fwd+adj passes over the first %d positions of the workload "
+                     "(oracle/ptycho_oracle.py, complex64, scipy.fft workers=%d), %.1f s"
+                     % (done // ns, ns, cores, t_used)}
+    # (2) single thread, numpy.fft
+    n1 = min(32, ns)
+    keep = (op.fft2_unnorm, op.ifft2_unnorm)
+    op.fft2_unnorm = lambda x: np.fft.fft2(x, axes=(-2, -1)).astype(x.dtype)
+    op.ifft2_unnorm = lambda x: np.fft.ifft2(x, axes=(-2, -1), norm="forward").astype(x.dtype)
+    try:
+        d1, t1 = 0, 0.0
+        while t1 < 3.0:
+            t0 = time.perf_counter()
+            g = op.fwd(prob["psi"], scan[:, :n1], prob["probe"], args.ndet)
+            op.adj(g, scan[:, :n1], prob["probe"], prob["nz"], prob["n"])
+            t1 += time.perf_counter() - t0
+            d1 += n1
+    finally:
+        op.fft2_unnorm, op.ifft2_unnorm = keep
+    out["single_thread"] = {"value": d1 / t1, "unit": "patterns/s", "cores": 1,
+                            "sample": "%d fwd+adj passes over %d positions, numpy.fft, one thread, %.1f s" % (d1 // n1, n1, t1)}
+    # (3) CG iterations/s of the oracle loop (reference loop restated in NumPy), 64 positions, extrapolated
+    R = prob.get("raster", 64)
+    idx = (np.arange(8)[:, None] * R + np.arange(8)[None, :]).ravel()          # an 8 x 8 corner of the raster
+    sc = np.ascontiguousarray(prob["scan"][:, idx])
+    span = int(np.ceil(sc.max())) + args.nprb + 2
+    psi = np.ascontiguousarray(prob["psi"][:, :span, :span])
+    ora = cgo.OracleSolver(len(idx), args.nprb, args.ndet, 1, span, span)
+    with scipy.fft.set_workers(cores), warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        data = (np.abs(ora.fwd(psi, sc, prob["probe"])) ** 2).astype(np.float32)
+        t0 = time.perf_counter()
+        niter = 2
+        ora.run(data, np.ones_like(psi), sc.copy(), prob["probe"][:, None].copy(), piter=niter)
+        tcg = time.perf_counter() - t0
+    nfull = prob["scan"].shape[1]
+    out["cg"] = {"value": niter / tcg * len(idx) / nfull, "unit": "CG iterations/s at %d positions (EXTRAPOLATED)" % nfull,
+                 "cores": cores, "measured_it_s_on_sample": niter / tcg,
+                 "sample": "%d iterations of oracle/cg_oracle.py on %d positions (8 x 8 corner of the raster, object cropped "
+                           "to %d^2), scipy.fft workers=%d, %.1f s; extrapolated linearly in the number of positions"
+                           % (niter, len(idx), span, cores, tcg)}
+    return out
 
 
 def main():
@@ -167,7 +209,7 @@ def main():
     prb_h = syn.gaussian_probe(nprb)
     rng_r = np.random.default_rng(1234 + 17 * rank)
     scan_h = syn.raster_scan(R, R, step, rng_r, y0=float(rank * R * step))
-    prob = {"psi": psi_h, "probe": prb_h, "scan": scan_h, "nz": nz, "n": n}
+    prob = {"psi": psi_h, "probe": prb_h, "scan": scan_h, "nz": nz, "n": n, "raster": R}
 
     dev = torch.device("cuda", local)
     psi = torch.as_tensor(psi_h, device=dev)
@@ -237,6 +279,23 @@ def main():
         elapsed = float(t.item())
     ms_per_step = 1e3 * elapsed / args.steps
     value = ngpu * nscan * args.steps / elapsed
+
+    # The timed steps reuse the position order of the first call (the scan tensor is unchanged: option trust_order).
+    # A caller whose positions change between calls pays the sort in both operators: same step, order forgotten
+    # before each operator call (local work only: no collective in this loop).
+    def sorted_step():
+        slv._scan_key = None
+        g = slv.fwd(psi, scan, prb, out=g_buf)
+        slv._scan_key = None
+        slv.adj(g, scan, prb, out=upd_buf)
+    for _ in range(args.warmup):
+        sorted_step()
+    torch.cuda.synchronize()
+    t0s = time.perf_counter()
+    for _ in range(args.steps):
+        sorted_step()
+    torch.cuda.synchronize()
+    ms_per_step_sorting = 1e3 * (time.perf_counter() - t0s) / args.steps
 
     # ---- live per-kernel timing (HIP events inside the library, launch stream) --
     slv.profile(True)
@@ -336,6 +395,27 @@ def main():
                 print("strong-scaling CG run failed: %r" % (e,), file=sys.stderr)
                 strong = None
                 data = None
+        screened = None
+        if not dist:
+            # the same loop on the oracle-validated family of problems: the probe carries a random phase screen, so the
+            # model covers the whole detector from the flat start and the trajectory is well conditioned (the smooth
+            # probe's is carried by rounding noise: tests/test_oracle_divergence.py); tests/test_hip_configs.py checks
+            # this geometry against the oracle at 8 x 8 positions
+            rs = np.random.default_rng(4242)
+            prb_s = torch.as_tensor((prb_h * np.exp(2j * np.pi * rs.random(prb_h.shape[-2:]))).astype(np.complex64), device=dev)
+            if data is None or g_buf is None:
+                g_buf = torch.empty((1, nscan, ndet, ndet), dtype=torch.complex64, device=dev)
+            data_s = (torch.abs(slv.fwd(psi, scan, prb_s, out=g_buf)) ** 2).contiguous()
+            g_buf = None
+            slv.run(data_s, psi0, scan.clone(), prb_s[:, None].clone(), piter=2)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            slv.run(data_s, psi0, scan.clone(), prb_s[:, None].clone(), piter=args.cg_iters)
+            torch.cuda.synchronize()
+            dts = time.perf_counter() - t0
+            screened = {"cg_screened_iterations_per_s": args.cg_iters / dts,
+                        "cg_screened_config": "same geometry and loop, probe x random phase screen (the oracle-checked, well-conditioned variant)"}
+            del data_s
         cg = {"cg_iterations_per_s": args.cg_iters / dt, "cg_iters_timed": args.cg_iters,
               "cg_ms_per_iteration": dt / args.cg_iters * 1e3,
               "cg_config": "gaussian, 1 mode, no probe recovery, position correction on (reference loop, sequenced by "
@@ -343,13 +423,19 @@ def main():
                            + (" (weak: %d positions per GPU)" % nscan if ngpu > 1 else "")}
         if strong:
             cg.update(strong)
+        if screened:
+            cg.update(screened)
         del data
 
     out = {
         "metric": "fwd+adj patterns/s",
         "value": value, "unit": "patterns/s",
         "n_gpus": ngpu, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": ms_per_step, "ms_per_step_sorting_every_call": ms_per_step_sorting,
+        "timed_region_note": "value / ms_per_step: the position order is computed once (scan unchanged between calls); "
+                             "ms_per_step_sorting_every_call: the same pair with the order recomputed in fwd and in adj"
+                             + (" (no all-reduce in this second loop)" if ngpu > 1 else ""),
+        "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "%d scan positions/GPU x (%dx%d) detector, complex64, nprb=%d, "
                                "1 probe mode, object %dx%d, raster step %d px + jitter "

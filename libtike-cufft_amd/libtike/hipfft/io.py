@@ -60,7 +60,7 @@ class PtychoDataset:
                        & (positions[:, 0] >= 0) & (positions[:, 0] < view_dims[0]))[0]
         positions = np.array(positions[ids], dtype=np.float32, order="C")
         data = np.ascontiguousarray(data[ids])              # :98-100
-        angle = rec["rotation_angle"] if "rotation_angle" in rec else None
+        angle = rec.get("rotation_angle")                   # None for a missing key OR a missing HDF5 attribute
         return cls(pid, data, positions, probes, None if angle is None else float(angle))
 
     @classmethod

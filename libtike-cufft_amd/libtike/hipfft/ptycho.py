@@ -703,6 +703,7 @@ class CGPtychoSolver(PtychoHIP):
         if st is None or st.device != dev:
             st = self._cg_state = torch.zeros(nat.ST_WORDS, dtype=torch.float64, device=dev)
             st[nat.ST_HINT:nat.ST_HINT + 2] = 14.0
+        st[nat.ST_GAMMA_PSI:nat.ST_GAMMA_PRB + 1] = 0.0       # a run without probe recovery logs step 0, as the reference prints
         h = self._h
         sp, costs = _ptr(st), st[nat.ST_COSTS:nat.ST_COSTS + nat.ST_NCOSTS]
         ones = self.__dict__.get("_ones_probe")
@@ -1050,13 +1051,15 @@ class CGPtychoSolver(PtychoHIP):
         assert probe.ndim == 4, "probe needs 4 dimensions, not %d" % probe.ndim
         nmodes = probe.shape[1]
         pow2 = self.ndet >= 16 and (self.ndet & (self.ndet - 1)) == 0   # the fused CG stages use the power-of-two plans
-        if self.fused and model == "gaussian" and pow2 and nmodes <= 8:
+        # several modes: the compact slot layout runs its line search over position ranges, which needs the windowed
+        # column pass (ndet <= 512); larger detectors take the statement-by-statement loop
+        if self.fused and model == "gaussian" and pow2 and nmodes <= 8 and (nmodes == 1 or self.ndet <= 512):
             # The fused loops run on the deterministic adjoints unless told otherwise: with float atomics (the
             # reference's kernels.cu:73-80) two runs of the same problem take different line-search paths -- near a
             # flat start the accept / reject decisions sit on the last float32 digit of the cost -- and differ by
             # +-10 % in time (tools/cg_variance.py).  In the loop the fixed-point scale comes from the projection
             # stage, so this costs no extra pass.
-            det = self.reproducible and not self._det and self.ndet <= 512
+            det = self.reproducible and not self._det and self.ndet <= 512 and int(nat.get(self._h, 101)) == 1
             if det:
                 nat.check(nat.set_option(self._h, b"deterministic", 1))
             try:

@@ -105,6 +105,25 @@ def test_fused_multimode_matches_unfused(pt):
     assert np.abs(rf["psi"] - want["psi"]).max() < 2e-4
 
 
+def test_two_modes_on_a_1024_detector(pt):
+    """ndet = 1024 has no LDS window (the compact multi-mode layout needs one): two probe modes on 4 positions must run
+    -- through the statement-by-statement loop on the un-windowed operators -- and track the oracle."""
+    ndet = 1024
+    p = syn.make_problem(2, 2, 8, ndet, ndet, seed=9)
+    rng = np.random.default_rng(10)
+    probe = (syn.hermite_modes(ndet, 2) * np.exp(2j * np.pi * rng.random((ndet, ndet)))).astype(np.complex64)
+    ora = cg.OracleSolver(p["nscan"], ndet, ndet, 1, p["nz"], p["n"])
+    data = sum(np.abs(ora.fwd(p["psi"], p["scan"], probe[:, k])) ** 2 for k in range(2)).astype(np.float32)
+    want = ora.run(data.copy(), np.ones_like(p["psi"]), p["scan"].copy(), probe.copy(), piter=2)
+    with pt.CGPtychoSolver(p["nscan"], ndet, ndet, 1, p["nz"], p["n"]) as slv:
+        slv.verbose, slv.log_every = False, 1
+        got = slv.run_batch(data.copy(), np.ones_like(p["psi"]), p["scan"].copy(), probe.copy(), piter=2)
+        hist = list(slv.history)
+    for a, b in zip(hist, ora.history):
+        assert a[1] == b[1] and abs(a[3] - b[3]) <= 1e-4 * abs(b[3]), (a, b)
+    assert np.abs(got["psi"] - want["psi"]).max() < 2e-4 * np.abs(want["psi"]).max()
+
+
 def test_two_angles_per_call_fused_and_unfused(pt):
     """ptheta = 2: two angular views solved in one call (shared scalars a, b and one joint
     line search, as in the reference's run); fused kernels vs the torch loop vs the oracle."""
