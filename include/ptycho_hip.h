@@ -233,6 +233,24 @@ int ptycho_cg_prb_dir(ptycho_handle h, double* state, int first, double nscan_to
                       const void* scan, const void* data, void* gprb, void* gprb0, void* dprb, void* stream);
 int ptycho_cg_prb_finish(ptycho_handle h, double* state, void* prb, const void* dprb, void* stream);
 
+/* Line searches of the multi-mode loop (compact slot layout) on the same device-resident state -- the host enqueues the
+ * worst case and never reads a cost back (src/libtike/cufft/ptycho.py:274-276 synchronises once per trial):
+ *   ptycho_cg_ls_begin      reset the search state of kind `which` (0 object, 1 probe); first pass sized from the last accepted index
+ *   ptycho_cg_ls_obj_chunk  one chunk of an object-search pass: column passes of fwd(dpsi, prbs[k]) for the chunk's positions
+ *                           (all modes, shared slot) + the line-search pass over them; chunk 0 stores the costs, the others add
+ *                           (:383-393 with the sums over the modes of :386-391).  all-reduce after the last chunk: state[COSTS .. +119)
+ *   ptycho_cg_ls_prb_pass   one pass of the probe search of mode `mode` (pair slot A(mode) / shared slot; p1 = inten) (:451-461)
+ *   ptycho_cg_ls_decide     line_search_sqr on the costs of the pass (:253-281); next_groups = groups of 16 step lengths the
+ *                           next pass prices (0: none follows).  Passes issued after the search is resolved return at once,
+ *                           their column passes included.
+ *   ptycho_cg_cross_dev     ptycho_cg_cross with gamma read from device memory (the accepted step never visits the host) */
+int ptycho_cg_ls_begin(ptycho_handle h, double* state, int which, void* stream);
+int ptycho_cg_ls_obj_chunk(ptycho_handle h, double* state, int chunk, const void* dpsi, const void* scan,
+                           const void* const* prbs, const void* data, const double* ab, void* stream);
+int ptycho_cg_ls_prb_pass(ptycho_handle h, double* state, int mode, const void* data, const void* inten, void* stream);
+int ptycho_cg_ls_decide(ptycho_handle h, double* state, int which, int next_groups, void* stream);
+int ptycho_cg_cross_dev(ptycho_handle h, int slot1, int slot2, const double* gamma_dev, void* image_product, void* stream);
+
 /* Tuning knobs: "chunk" (positions per launch pair, 0 = default);
  * "window" (1 = LDS overlap-add object adjoint [default], 0 = direct atomics);
  * "trust_order" (1 = the caller vouches that the scan buffer passed to the next calls is the

@@ -296,6 +296,7 @@ __global__ __launch_bounds__(ColCfg<N>::NT) void k_cols_gatherwin(const ColArgs 
     // gathered from the window ONCE and multiplied by the NM probe strips (all in VGPRs), giving the
     // strips of NM farplanes dstm[k] (ptycho.py:330-333 calls fwd once per mode and gathers each time).
     static_assert(NM == 1 || (MODE == M_FWD && !SPLIT), "several probe modes: un-split forward pass only");
+    if (MODE == M_FWD && a.skip && *a.skip != 0.0) return;   // uniform over the grid
     using P = Plan<N>;
     constexpr int DIR = (MODE == M_FWD) ? -1 : +1;
     using F = Fft<P, DIR>;

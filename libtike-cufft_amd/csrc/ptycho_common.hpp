@@ -60,6 +60,9 @@ struct ColArgs {
     // float atomics on dst; det_scale_of(det) is the power of two that converts a float to that fixed point
     long long* det_acc;
     DetScale det;
+    // forward passes of a line search whose decisions live on the device: the launch returns at once if *skip != 0
+    // (the search is already resolved; the host enqueues the worst case and never reads the state back)
+    const double* skip;
 #ifdef PTY_STAMPS
     unsigned long long* stamps;   // diagnostic build only (tools/stamps.py): per-phase cycle totals, 12 words per kernel role
 #endif

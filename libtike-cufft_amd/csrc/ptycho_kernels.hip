@@ -1548,7 +1548,7 @@ int launch_gatherwin_modes(ptycho_handle h, ColArgs a, hipStream_t st) {
 
 template <int N>
 int do_cg_fwd_cols_modes(ptycho_handle h, int nmodes, c32* const* dst, const c32* f, const float* scan, const c32* const* prbs,
-                         int k_begin, int k_end, hipStream_t st) {
+                         int k_begin, int k_end, hipStream_t st, const double* skip = nullptr) {
     const Geom& ge = h->ge;
     int strip0, nstrips;
     strip_range<N>(ge, strip0, nstrips);
@@ -1557,6 +1557,7 @@ int do_cg_fwd_cols_modes(ptycho_handle h, int nmodes, c32* const* dst, const c32
     ColArgs ca{};
     ca.src = f; ca.scan = scan; ca.table = h->table; ca.ge = ge; ca.order = h->order;
     ca.k_begin = k_begin; ca.k_end = k_end; ca.strip0 = strip0; ca.nstrips = nstrips;
+    ca.skip = skip;
     static const int nm_max = exp_env("PTYCHO_HIP_NMMAX", 4);   // comparison knob
     int k = 0;
     while (k < nmodes) {
@@ -1597,8 +1598,17 @@ int do_ls_chunk(ptycho_handle h, RowFusedArgs a, hipStream_t st) { return do_cg_
 
 }  // namespace
 
+namespace {
+int fwd_cols_modes_impl(ptycho_handle h, int nmodes, int mode0, const void* f, const void* scan,
+                        const void* const* prbs, int into_b, int chunk, void* stream, const double* skip);
+}
 extern "C" int ptycho_cg_fwd_cols_modes(ptycho_handle h, int nmodes, int mode0, const void* f, const void* scan,
                                         const void* const* prbs, int into_b, int chunk, void* stream) {
+    return fwd_cols_modes_impl(h, nmodes, mode0, f, scan, prbs, into_b, chunk, stream, nullptr);
+}
+namespace {
+int fwd_cols_modes_impl(ptycho_handle h, int nmodes, int mode0, const void* f, const void* scan,
+                        const void* const* prbs, int into_b, int chunk, void* stream, const double* skip) {
     int rc = check_handle(h);
     if (rc) return rc;
     if (!f || !scan || !prbs || nmodes < 1 || mode0 < 0 || mode0 + nmodes > kMaxModes) return fail(PTYCHO_ERR_ARG, "bad operand");
@@ -1628,8 +1638,9 @@ extern "C" int ptycho_cg_fwd_cols_modes(ptycho_handle h, int nmodes, int mode0, 
         pr[k] = (const c32*)prbs[k];
     }
     hipStream_t st = (hipStream_t)stream;
-    PTY_DISPATCH(h->ge.ndet, (do_cg_fwd_cols_modes<NN>(h, nmodes, dst, (const c32*)f, (const float*)scan, pr, k_begin, k_end, st)));
+    PTY_DISPATCH(h->ge.ndet, (do_cg_fwd_cols_modes<NN>(h, nmodes, dst, (const c32*)f, (const float*)scan, pr, k_begin, k_end, st, skip)));
 }
+}  // namespace
 
 extern "C" int ptycho_cg_linesearch_chunk(ptycho_handle h, int chunk, const void* data, const double* ab, double gamma0,
                                           int ncand, double* costs, void* stream) {
@@ -1657,3 +1668,102 @@ extern "C" int ptycho_cg_linesearch_chunk(ptycho_handle h, int chunk, const void
     hipStream_t st = (hipStream_t)stream;
     PTY_DISPATCH(h->ge.ndet, (do_ls_chunk<NN>(h, a, st)));
 }
+
+
+// ---- line searches of the multi-mode loop on the device-resident state (ptycho.py:383-393, 451-461 with nmodes > 1) ----
+namespace {
+__global__ void k_cg_ls_begin(double* __restrict__ st, const int which) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) ls_prepare_dev(st, which);
+}
+template <int N>
+int do_ls_modes(ptycho_handle h, RowFusedArgs a, hipStream_t st) { return do_cg_rows<N, EP_LINESEARCH_M>(h, a, st); }
+}  // namespace
+
+extern "C" {
+
+int ptycho_cg_ls_begin(ptycho_handle h, double* state, int which, void* stream) {
+    int rc = check_stage(h, state);
+    if (rc) return rc;
+    if (which < 0 || which > 1) return fail(PTYCHO_ERR_ARG, "which must be 0 (object) or 1 (probe)");
+    hipLaunchKernelGGL(k_cg_ls_begin, dim3(1), dim3(1), 0, (hipStream_t)stream, state, which);
+    HIP_TRY(hipGetLastError());
+    return PTYCHO_OK;
+}
+
+int ptycho_cg_ls_decide(ptycho_handle h, double* state, int which, int next_groups, void* stream) {
+    int rc = check_stage(h, state);
+    if (rc) return rc;
+    if (which < 0 || which > 1 || next_groups < 0 || next_groups > kLsGroupsMax) return fail(PTYCHO_ERR_ARG, "bad line-search decision");
+    hipLaunchKernelGGL(k_cg_ls_decide, dim3(1), dim3(1), 0, (hipStream_t)stream, state, which,
+                       which == 0 ? (int)PTYCHO_ST_GAMMA_PSI : (int)PTYCHO_ST_GAMMA_PRB, next_groups);
+    HIP_TRY(hipGetLastError());
+    return PTYCHO_OK;
+}
+
+int ptycho_cg_ls_obj_chunk(ptycho_handle h, double* state, int chunk, const void* dpsi, const void* scan,
+                           const void* const* prbs, const void* data, const double* ab, void* stream) {
+    int rc = check_stage(h, state);
+    if (rc) return rc;
+    if (!dpsi || !scan || !prbs || !data) return fail(PTYCHO_ERR_ARG, "null operand");
+    if (!h->compact_modes || chunk < 0 || chunk >= h->sort_chunks) return fail(PTYCHO_ERR_ARG, "chunked line search needs the compact slot layout");
+    const int M = h->compact_modes;
+    // direction column passes of this chunk, all modes side by side in the shared slot (skipped once the search is resolved)
+    rc = fwd_cols_modes_impl(h, M, 0, dpsi, scan, prbs, 1, chunk, stream, state + PTYCHO_ST_LS_RESOLVED);
+    if (rc) return rc;
+    const long long total = (long long)h->ge.ptheta * h->ge.nscan;
+    const long long pc = (total + h->sort_chunks - 1) / h->sort_chunks;
+    const long long p0 = chunk * pc, p1 = (chunk + 1) * pc < total ? (chunk + 1) * pc : total;
+    if (p1 <= p0) return PTYCHO_OK;
+    const size_t tile = (size_t)h->ge.ndet * h->ge.ndet;
+    RowFusedArgs a{};
+    for (int k = 0; k < M; ++k) {
+        if (!slot_ready(h, slot_a(h, k)) || !slot_ready(h, slot_b(h, 0))) return fail(PTYCHO_ERR_ARG, "work slot is empty");
+        a.sm[2 * k] = h->work[slot_a(h, k)] + (size_t)p0 * tile;
+        a.sm[2 * k + 1] = h->work[slot_b(h, 0)] + (size_t)k * pc * tile;
+    }
+    a.nmodes = M;
+    a.data = (const float*)data + (size_t)p0 * tile; a.ab = ab;
+    a.st = state; a.sums = state + PTYCHO_ST_COSTS; a.gamma0 = 1.0f; a.ncand = kMaxCand;
+    a.overwrite = chunk == 0 ? 1 : 0;      // the chunks of one pass accumulate; the first one stores
+    a.nrows = (p1 - p0) * h->ge.ndet;
+    hipStream_t st = (hipStream_t)stream;
+    PTY_DISPATCH(h->ge.ndet, (do_ls_modes<NN>(h, a, st)));
+}
+
+int ptycho_cg_ls_prb_pass(ptycho_handle h, double* state, int mode, const void* data, const void* inten, void* stream) {
+    int rc = check_stage(h, state);
+    if (rc) return rc;
+    if (!data || !inten) return fail(PTYCHO_ERR_ARG, "null operand");
+    if (mode < 0 || mode >= kMaxModes) return fail(PTYCHO_ERR_ARG, "modes must lie in [0, 8)");
+    if (!slot_ready(h, slot_a(h, mode)) || !slot_ready(h, slot_b(h, mode))) return fail(PTYCHO_ERR_ARG, "work slot is empty");
+    RowFusedArgs a{};
+    a.sm[0] = h->work[slot_a(h, mode)];
+    a.sm[1] = h->work[slot_b(h, mode)];
+    a.nmodes = 1;
+    a.data = (const float*)data; a.inten = (const float*)inten;
+    a.st = state; a.sums = state + PTYCHO_ST_COSTS; a.gamma0 = 1.0f; a.ncand = kMaxCand;
+    a.overwrite = 1;
+    hipStream_t st = (hipStream_t)stream;
+    PTY_DISPATCH(h->ge.ndet, (do_ls_modes<NN>(h, a, st)));
+}
+
+int ptycho_cg_cross_dev(ptycho_handle h, int slot1, int slot2, const double* gamma_dev, void* image_product, void* stream) {
+    int rc = check_handle(h);
+    if (rc) return rc;
+    if (!gamma_dev) return fail(PTYCHO_ERR_ARG, "null operand");
+    if (!image_product) {   // NULL: the image product lives in work slot 2 (free during the position correction)
+        rc = ensure_work(h, 2);
+        if (rc) return rc;
+        if (slot1 == 2 || slot2 == 2) return fail(PTYCHO_ERR_ARG, "slot 2 is taken by the image product");
+        image_product = h->work[2];
+    }
+    if (!slot_ready(h, slot1) || !slot_ready(h, slot2)) return fail(PTYCHO_ERR_ARG, "work slot is empty");
+    RowFusedArgs a{};
+    a.s1 = h->work[slot1]; a.s2 = h->work[slot2]; a.out = h->work[slot2]; a.ip = (c32*)image_product;
+    a.gamma_dev = gamma_dev;
+    h->slot_max_ok[slot2] = false;
+    hipStream_t st = (hipStream_t)stream;
+    PTY_DISPATCH(h->ge.ndet, (do_cg_rows<NN, EP_CROSS>(h, a, st)));
+}
+
+}  // extern "C"

@@ -622,8 +622,9 @@ class CGPtychoSolver(PtychoHIP):
         if ones is None or ones.shape != probe[:, 0].shape or ones.device != probe.device:
             ones = self._ones_probe = torch.ones_like(probe[:, 0])
         if not (self.fused and self.ptheta == 1):
+            g32 = gammapsi.to(torch.float32) if isinstance(gammapsi, torch.Tensor) else gammapsi
             tmp1 = self.fwd(psi, scan, ones)[0]
-            tmp2 = self.fwd(psi + gammapsi * dpsi, scan, ones)[0]
+            tmp2 = self.fwd(psi + g32 * dpsi, scan, ones)[0]
             return register_translation_batch(tmp1, tmp2, upsample_factor=100, space="fourier", op=self)
         self._cg_fwd_cols(0, psi, scan, ones)
         self._cg_fwd_cols(1, dpsi, scan, ones)
@@ -632,7 +633,10 @@ class CGPtychoSolver(PtychoHIP):
         in_slot = probe.shape[1] >= 3 and _zoom_real_factors(self.ndet, 150, 100, psi.device) is not None \
             and self.ndet % 16 == 0 and self.ndet <= 1024
         ip = None if in_slot else torch.empty((self.nscan, self.ndet, self.ndet), dtype=torch.complex64, device=psi.device)
-        nat.check(nat.cg_cross(self._h, 0, 1, float(gammapsi), _ptr(ip) if ip is not None else None, _stream()))
+        if isinstance(gammapsi, torch.Tensor):      # the accepted step lives on the device (float64 word)
+            nat.check(nat.cg_cross_dev(self._h, 0, 1, _ptr(gammapsi), _ptr(ip) if ip is not None else None, _stream()))
+        else:
+            nat.check(nat.cg_cross(self._h, 0, 1, float(gammapsi), _ptr(ip) if ip is not None else None, _stream()))
         best = torch.empty(self.nscan, dtype=torch.int64, device=psi.device)
         nat.check(nat.cg_argmax(self._h, 1, _ptr(best), _stream()))
         shifts = _zoom_shifts_native(self, ip, best, 100)
@@ -865,36 +869,6 @@ class CGPtychoSolver(PtychoHIP):
         return {"psi": psi, "probe": probe}
 
     # -- fused multi-mode gaussian loop ----------------------------------------------------
-    def _modes_line_search(self, mode0, nmodes, data, inten, ab, costs, which):
-        """All trials of ``line_search_sqr`` (ptycho.py:253-281) with p1, p2, p3 summed over the
-        mode pairs (slot 2k, slot 2k+1) in the row pass's registers (``ptycho_cg_linesearch_modes``);
-        pass sizing as in ``_fused_line_search``."""
-        hints = self.__dict__.setdefault("_ls_hint", {})
-        ncand = min(16, max(2, hints.get(which, 14) + 2))
-        gamma0 = 1.0
-        tried = 0
-        while True:
-            costs.zero_()
-            nat.check(nat.cg_linesearch_modes(self._h, mode0, nmodes, _ptr(data),
-                                              _ptr(inten) if inten is not None else None,
-                                              _ptr(ab) if ab is not None else None,
-                                              gamma0, ncand, _ptr(costs), _stream()))
-            self._allreduce(costs)
-            c = costs.to(torch.float32).cpu().numpy()
-            step = gamma0
-            for j in range(ncand):
-                if not (c[j] > c[ncand]):
-                    hints[which] = tried + j
-                    return step
-                if step < 1e-32:
-                    warnings.warn("Line search failed for conjugate gradient.")
-                    hints[which] = 14
-                    return 0
-                step *= 0.5
-            gamma0 = step
-            tried += ncand
-            ncand = 16
-
     def _run_fused_multi(self, data, psi, scan, probe, piter, recover_prb):
         """``CGPtychoSolver.run`` (ptycho.py:283-488), gaussian model, 2..8 incoherent probe modes.
 
@@ -906,8 +880,13 @@ class CGPtychoSolver(PtychoHIP):
         modes: projected residual of one mode at a time, direction column passes.  The summed intensity
         is a float32 array written once (no per-mode farplane is ever materialised); the object line
         search, which needs fwd(dpsi, probe_k) of every mode at once, runs over M position ranges with
-        the M direction column passes of a range side by side in the shared slot
-        (``ptycho_cg_linesearch_chunk``): M + 1 farplanes instead of 2 M, same work."""
+        the M direction column passes of a range side by side in the shared slot: M + 1 farplanes instead
+        of 2 M, same work.
+
+        Device resident since round 3: a, b, the line-search costs and the accepted step lengths stay in the float64
+        state vector of the native stages; every search is enqueued in full (passes of <= 16, 16, 32, 64 step lengths,
+        ``ptycho_cg_ls_obj_chunk / ls_prb_pass / ls_decide``: passes after the deciding one return at once, their column
+        passes included) and the host reads the state back only when it logs."""
         dev = data.device
         M = probe.shape[1]
         data = self._operand(data, torch.float32, (self.ptheta, self.nscan, self.ndet, self.ndet), "data")
@@ -917,55 +896,65 @@ class CGPtychoSolver(PtychoHIP):
         nat.check(nat.set_option(self._h, b"compact_modes", M))
         self._scan_key = None                   # the position order becomes chunk-major: sort again
         nscan_total = self._nscan_total()
-        sums = torch.zeros(2, dtype=torch.float64, device=dev)
-        cost = torch.zeros(1, dtype=torch.float64, device=dev)
-        scratch_cost = torch.zeros(1, dtype=torch.float64, device=dev)
-        costs = torch.zeros(33, dtype=torch.float64, device=dev)
+        st = self.__dict__.get("_cg_state")
+        if st is None or st.device != dev:
+            st = self._cg_state = torch.zeros(nat.ST_WORDS, dtype=torch.float64, device=dev)
+            st[nat.ST_HINT:nat.ST_HINT + 2] = 14.0
+        st[nat.ST_GAMMA_PSI:nat.ST_GAMMA_PRB + 1] = 0.0
+        sp = _ptr(st)
+        sums = st[nat.ST_A:nat.ST_A + 2]                    # a, b (views of the state vector)
+        cost = st[nat.ST_COST:nat.ST_COST + 1]
+        scratch_cost = st[nat.ST_COST2:nat.ST_COST2 + 1]
+        costs = st[nat.ST_COSTS:nat.ST_COSTS + nat.ST_NCOSTS]
+        gpsi_w = st[nat.ST_GAMMA_PSI:nat.ST_GAMMA_PSI + 1]
+        gprb_w = st[nat.ST_GAMMA_PRB:nat.ST_GAMMA_PRB + 1]
+        dist_on = self.group is not None
         inten = torch.empty_like(data)
         mode = lambda arr, k: arr[:, k].contiguous()
         A = lambda k: k              # column pass of fwd(psi, probe_k)
         B = M                        # shared: residual of one mode, then column passes of fwd(direction, .)
         vpp = ctypes.c_void_p * M
+        passes = (1, 2, 4, 0)        # groups of 16 step lengths the NEXT pass prices (after the hint-sized first one)
 
-        def fwd_cols_all(obj, modes, into_b=0, chunk=0):     # one launch per <= 4 modes, shared patch gather
-            self._note_scan(scan)
+        def mode_ptrs(modes):
             keep = [mode(modes, k) for k in range(M)]
-            ptrs = vpp(*[t.data_ptr() for t in keep])
-            nat.check(nat.cg_fwd_cols_modes(self._h, M, 0, _ptr(obj), _ptr(scan), ptrs, into_b, chunk, _stream()))
+            return keep, vpp(*[t.data_ptr() for t in keep])
+
+        def fwd_cols_all(obj, modes):           # one launch per <= 4 modes, shared patch gather
+            self._note_scan(scan)
+            keep, ptrs = mode_ptrs(modes)
+            nat.check(nat.cg_fwd_cols_modes(self._h, M, 0, _ptr(obj), _ptr(scan), ptrs, 0, 0, _stream()))
 
         def sum_intensity(stats=None):          # inten = sum_k |slot A(k)|^2 (+ a, b of :342-343) in one pass
             nat.check(nat.cg_intensity_modes(self._h, M, _ptr(inten), _ptr(data),
                                              _ptr(stats) if stats is not None else None, _stream()))
 
-        def object_line_search(ab):
-            """``_modes_line_search`` for all modes, chunk by chunk; t1_k = (a/b) * slot A(k) (old probe),
-            t2_k = column pass of fwd(dpsi, probe_k) (rescaled probe) in part k of the shared slot."""
-            hints = self.__dict__.setdefault("_ls_hint", {})
-            ncand = min(16, (max(2, hints.get("psi", 14) + 2) + 3) & ~3)
-            gamma0, tried = 1.0, 0
-            while True:
-                costs.zero_()
+        def object_line_search():
+            """ptycho.py:383-393 for all modes, chunk by chunk; t1_k = (a/b) * slot A(k) (old probe), t2_k = column
+            pass of fwd(dpsi, probe_k) (rescaled probe) in part k of the shared slot; 0.5 * step -> state[GAMMA_PSI]."""
+            self._note_scan(scan)
+            keep, ptrs = mode_ptrs(probe)
+            S = _stream()
+            nat.check(nat.cg_ls_begin(self._h, sp, 0, S))
+            for nxt in passes:
                 for c in range(M):
-                    fwd_cols_all(dpsi, probe, into_b=1, chunk=c)
-                    nat.check(nat.cg_linesearch_chunk(self._h, c, _ptr(data), _ptr(ab), gamma0, ncand,
-                                                      _ptr(costs), _stream()))
-                self._allreduce(costs)
-                cc = costs.to(torch.float32).cpu().numpy()
-                step = gamma0
-                for j in range(ncand):
-                    if not (cc[j] > cc[ncand]):
-                        hints["psi"] = tried + j
-                        return step
-                    if step < 1e-32:
-                        warnings.warn("Line search failed for conjugate gradient.")
-                        hints["psi"] = 14
-                        return 0
-                    step *= 0.5
-                gamma0, tried, ncand = step, tried + ncand, 16
+                    nat.check(nat.cg_ls_obj_chunk(self._h, sp, c, _ptr(dpsi), _ptr(scan), ptrs, _ptr(data), _ptr(sums), S))
+                if dist_on:
+                    self._allreduce(costs)
+                nat.check(nat.cg_ls_decide(self._h, sp, 0, nxt, S))
+
+        def probe_line_search(m):
+            """ptycho.py:451-461: p1 = summed intensity, p2 = |fwd(psi, dprb_m)|^2, p3 = 2 Re(fwd(psi, probe_m) conj(.))."""
+            S = _stream()
+            nat.check(nat.cg_ls_begin(self._h, sp, 1, S))
+            for nxt in passes:
+                nat.check(nat.cg_ls_prb_pass(self._h, sp, m, _ptr(data), _ptr(inten), S))
+                if dist_on:
+                    self._allreduce(costs)
+                nat.check(nat.cg_ls_decide(self._h, sp, 1, nxt, S))
 
         dpsi = gradpsi0 = None
         dprb = gradprb0 = gradprb = None
-        gammaprb = 0
         if self.verbose:
             print("# congujate gradient parameters\n"
                   "iteration, step size object, step size probe, function min")
@@ -983,6 +972,7 @@ class CGPtychoSolver(PtychoHIP):
                 for k in range(M):                                                  # :349-356
                     pk = mode(probe, k)
                     # slot A(k) was made with the probe before its rescale: fpsi = (g s)(1/s)
+                    scratch_cost.zero_()
                     nat.check(nat.cg_project_multi(self._h, A(k), B, _ptr(data), _ptr(inten), _ptr(sums), 1,
                                                    _ptr(cost if k == 0 else scratch_cost), _stream()))
                     g = torch.zeros_like(gradpsi)
@@ -991,11 +981,12 @@ class CGPtychoSolver(PtychoHIP):
                 self._allreduce(gradpsi)
                 dpsi = _dy_direction(i, gradpsi, gradpsi0, dpsi)
                 gradpsi0 = gradpsi
-                gammapsi = 0.5 * object_line_search(sums)                           # :383-393
+                object_line_search()                                                # :383-393 -> state[GAMMA_PSI]
+                gamma32 = gpsi_w.to(torch.float32)
 
                 if i > 0:                                                           # :398-403
-                    scan[0, :] += self._position_shifts(psi, dpsi, gammapsi, scan, probe).to(scan.dtype)
-                psi = psi + gammapsi * dpsi
+                    scan[0, :] += self._position_shifts(psi, dpsi, gpsi_w, scan, probe).to(scan.dtype)
+                psi = psi + gamma32 * dpsi
 
                 # 2) probe step, one mode at a time ------------------------------------------
                 if recover_prb:                                                     # :409-465
@@ -1027,19 +1018,26 @@ class CGPtychoSolver(PtychoHIP):
                                 * dprb[:, m])
                         gradprb0[:, m] = gradprb[:, m]
                         self._cg_fwd_cols(B, psi, scan, mode(dprb, m))
-                        # p1 = summed intensity, p2 = |fwd(psi, dprb_m)|^2, p3 = 2 Re(fwd(psi, probe_m) conj(.))
-                        gammaprb = 0.5 * self._modes_line_search(m, 1, data, inten, None, costs, "prb%d" % m)
-                        probe[:, m] = probe[:, m] + gammaprb * dprb[:, m]
+                        probe_line_search(m)                                        # -> state[GAMMA_PRB]
+                        probe[:, m] = probe[:, m] + gprb_w.to(torch.float32) * dprb[:, m]
 
                 if i % self.log_every == 0:
-                    c = cost.clone()
-                    self._allreduce(c)
-                    self.history.append((i, float(gammapsi), float(gammaprb), float(c.to(torch.float32))))
+                    snap = st[:nat.ST_LS_FAILED + 1].clone()
+                    if dist_on:
+                        self._allreduce(snap[nat.ST_COST:nat.ST_COST + 1])
+                    snap = snap.cpu()
+                    self.history.append((i, float(snap[nat.ST_GAMMA_PSI]), float(snap[nat.ST_GAMMA_PRB]),
+                                         float(snap[nat.ST_COST].to(torch.float32))))
                     if self.verbose:
                         print("%4d, %.3e, %.3e, %.7e" % self.history[-1])
         finally:
             nat.check(nat.set_option(self._h, b"compact_modes", 0))
             self._scan_key = None
+        failed = int(st[nat.ST_LS_FAILED].item())
+        if failed:
+            st[nat.ST_LS_FAILED] = 0.0
+            for _ in range(failed):
+                warnings.warn("Line search failed for conjugate gradient.")
         return {"psi": psi, "probe": probe}
 
     def run(self, data, psi, scan, probe, piter, model="gaussian",
