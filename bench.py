@@ -105,6 +105,33 @@ def cfg3_figures(pt, syn, dev, iters):
                          "solver creation and the end of the run (work slots, scratch, intensity, registration, data 4 GiB)"}
 
 
+def generic_figures(pt, syn, dev):
+    """fwd+adj pair at a detector size that is not a power of two (the reference's tests/test_fsc.py crops to such
+    sizes): 4096 positions x (112 x 112), Bluestein lines + windowed overlap-add object adjoint."""
+    R, step, ndet = 64, 8, 112
+    nz, n = syn.object_size_for(R, R, step, ndet)
+    rng = np.random.default_rng(777)
+    psi = torch.as_tensor(syn.random_object(nz, n, rng), device=dev)
+    scan = torch.as_tensor(syn.raster_scan(R, R, step, rng), device=dev)
+    prb = torch.as_tensor(syn.gaussian_probe(ndet), device=dev)
+    slv = pt.PtychoCuFFT(R * R, ndet, ndet, 1, nz, n)
+    g = torch.empty((1, R * R, ndet, ndet), dtype=torch.complex64, device=dev)
+    o = torch.empty_like(psi)
+    for _ in range(5):
+        slv.adj(slv.fwd(psi, scan, prb, out=g), scan, prb, out=o)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(10):
+        slv.adj(slv.fwd(psi, scan, prb, out=g), scan, prb, out=o)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / 10 * 1e3
+    slv.free()
+    pair_bytes = 2.0 * (8.0 * R * R * ndet * ndet + 8.0 * nz * n + 8.0 * ndet * ndet + 8.0 * R * R)
+    return {"generic112_workload": "4096 positions x (112x112), nprb 112: detector size that is not a power of two (Bluestein path)",
+            "generic112_pair_ms": ms, "generic112_patterns_per_s": R * R / (ms * 1e-3),
+            "generic112_roofline_frac": pair_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+
+
 def cpu_baseline(args, prob):
     """The reference ships no CPU path (``array_module = cp`` only), so the CPU figures are the oracle's
     (SURVEY.md 8d), timed on this host: (1) fwd+adj patterns/s with scipy.fft on all cores -- ``value`` --,
@@ -459,6 +486,10 @@ def main():
             out.update(cfg3_figures(pt, syn, dev, args.cfg3_iters))
         except Exception as e:          # never let a secondary figure break the primary line
             print("configs[2] figures failed: %r" % (e,), file=sys.stderr)
+        try:
+            out.update(generic_figures(pt, syn, dev))
+        except Exception as e:
+            print("generic-size figures failed: %r" % (e,), file=sys.stderr)
     if dist:
         dist.barrier()
         dist.destroy_process_group()

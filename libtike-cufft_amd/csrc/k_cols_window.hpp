@@ -179,6 +179,9 @@ __global__ __launch_bounds__(ColCfg<N>::NT) void k_cols_adjwin(const ColArgs a, 
             // split kernel: no exchange went through the tile, so the "previous combine is done"
             // barrier sits here, after this position's transform, instead of at the end of the loop
             STAMP(2)      // transform + probe product
+#if defined(PTY_AB) && (PTY_AB & 1)
+            __builtin_amdgcn_sched_barrier(0);   // keep the transform ABOVE the barrier: it overlaps the other waves' combine tail
+#endif
             if (SPLIT) __syncthreads();
             STAMP(3)      // barrier: previous combine done
 #pragma unroll

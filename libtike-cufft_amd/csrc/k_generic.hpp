@@ -178,3 +178,103 @@ __global__ void k_adj_prb_generic(const c32* __restrict__ f, c32* __restrict__ p
         atomicAdd(o + 1, acc.y * (1.0f / (float)N));
     }
 }
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// Object adjoint for any detector size with the on-chip overlap-add of k_cols_adjwin (k_cols_window.hpp) instead of the
+// reference's eight float atomics per probe pixel (kernels.cu:69-81, k_adj_obj_generic above): the near field is already
+// fully transformed (Bluestein lines), so a workgroup only forms T = conj(c prb) near for a strip of 16 probe columns,
+// combines the four bilinear taps and adds them to an LDS window of the object that follows a run of SORTED positions;
+// rows are added to global memory once, when they slide out.  The window (nprb + 8 rows x 20 columns) is dynamic LDS.
+// Tile of the k-th sorted position: a.src + (k - a.k_begin) ndet^2.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_adjwin_generic(const ColArgs a, const int seglen) {
+    extern __shared__ c32 gwin[];
+    constexpr int C = 16, WC = C + kBucketPx, NT = 256;
+    const Geom ge = a.ge;
+    const int N = ge.ndet, H = ge.nprb + 8;
+    const int tid = threadIdx.x;
+    const int strip = blockIdx.x % a.nstrips, seg = blockIdx.x / a.nstrips;
+    const int ix0 = strip * C;                     // first probe column of the strip
+    const float cinv = 1.0f / (float)N;
+    const c32 zero = c32{0.0f, 0.0f};
+    for (int o = tid; o < H * WC; o += NT) gwin[o] = zero;
+    int t_w = -1, X0 = 0, Ybase = 0, Ytop = 0;     // live object rows [Ybase, Ytop), columns [X0, X0 + WC)
+
+    auto flush = [&](int ya, int yb) {             // add rows [ya, yb) to the object and clear them
+        if (yb <= ya) return;
+        const int cnt = (yb - ya) * WC;
+        for (int o = tid; o < cnt; o += NT) {
+            const int Y = ya + o / WC, col = o % WC;
+            const int slot = (Y % H) * WC + col;
+            const c32 v = gwin[slot];
+            gwin[slot] = zero;
+            const int X = X0 + col;
+            if ((v.x != 0.0f || v.y != 0.0f) && Y < ge.nz && X >= 0 && X < ge.n) {
+                float* op = reinterpret_cast<float*>(a.dst + ((size_t)t_w * ge.nz + Y) * ge.n + X);
+                atomicAdd(op, v.x);
+                atomicAdd(op + 1, v.y);
+            }
+        }
+    };
+    constexpr int NRG = NT / (C + 1), NITEM = (C + 1) * NRG;
+    const int rpt = (ge.nprb + 1 + NRG - 1) / NRG;  // output rows per item
+
+    const int kb = a.k_begin + seg * seglen;
+    const int ke = kb + seglen < a.k_end ? kb + seglen : a.k_end;
+    __shared__ RunMeta rm;
+    load_run(rm, a.order, a.scan, kb, ke, tid);
+    __syncthreads();
+    for (int k = kb; k < ke; ++k) {
+        const int p = uni_i(rm.p[k - kb]);
+        const int t = p / ge.nscan;
+        const Pos q = decode_xy(uni_f(rm.py[k - kb]), uni_f(rm.px[k - kb]), ge);
+        if (!q.valid) continue;                     // uniform
+        const c32* __restrict__ near = a.src + (size_t)(k - a.k_begin) * N * N;
+        const c32* __restrict__ prb = a.aux + (size_t)t * ge.nprb * ge.nprb;
+        __syncthreads();                            // the previous position's combine is done
+        const int Xa = q.sx + ix0;                  // object column of strip column cc = 0
+        const bool fitsw = (t == t_w) && Xa >= X0 && Xa + C < X0 + WC && q.sy >= Ybase;
+        if (!fitsw) {
+            flush(Ybase, Ytop);
+            t_w = t;
+            X0 = (q.sx / kBucketPx) * kBucketPx + ix0;
+            Ybase = q.sy;
+            Ytop = q.sy;
+        } else if (q.sy > Ybase) {
+            flush(Ybase, q.sy < Ytop ? q.sy : Ytop);
+            Ybase = q.sy;
+            if (Ytop < Ybase) Ytop = Ybase;
+        }
+        if (Ytop < q.sy + ge.nprb + 1) Ytop = q.sy + ge.nprb + 1;
+        __syncthreads();                            // flushed rows are clean before they re-enter at the top
+        // T(y, x) = conj(c prb[y][x]) near[y + pad][x + pad] for the 16 probe columns of THIS strip, zero elsewhere (the
+        // neighbouring strips add their own columns' taps to the shared boundary column)
+        auto Tat = [&](int y, int x) -> c32 {
+            if (y < 0 || y >= ge.nprb || x < ix0 || x >= ix0 + C || x >= ge.nprb) return zero;
+            return cmulc(near[(size_t)(y + ge.pad) * N + x + ge.pad], prb[(size_t)y * ge.nprb + x] * cinv);
+        };
+        const float w00 = (1.0f - q.fx) * (1.0f - q.fy), w01 = q.fx * (1.0f - q.fy);
+        const float w10 = (1.0f - q.fx) * q.fy, w11 = q.fx * q.fy;
+        for (int item = tid; item < NITEM; item += NT) {
+            const int cc = item % (C + 1), rg = item / (C + 1);
+            const int ixo = ix0 + cc;               // probe column of tap (., 0)
+            if (ixo > ge.nprb) continue;
+            const int y0 = rg * rpt;
+            int y1 = y0 + rpt;
+            if (y1 > ge.nprb + 1) y1 = ge.nprb + 1;
+            if (y0 >= y1) continue;
+            c32 up0 = Tat(y0 - 1, ixo), up1 = Tat(y0 - 1, ixo - 1);
+            int slot = (q.sy + y0) % H;
+            const int colw = Xa - X0 + cc;
+            for (int y = y0; y < y1; ++y) {
+                const c32 t00 = Tat(y, ixo), t01 = Tat(y, ixo - 1);
+                gwin[slot * WC + colw] += t00 * w00 + t01 * w01 + up0 * w10 + up1 * w11;   // kernels.cu:73-80
+                up0 = t00; up1 = t01;
+                slot = slot + 1 == H ? 0 : slot + 1;
+            }
+        }
+    }
+    __syncthreads();
+    flush(Ybase, Ytop);
+}

@@ -663,13 +663,39 @@ int do_adj_generic(ptycho_handle h, c32* f, const c32* g, const float* scan, c32
     const Geom& ge = h->ge;
     const long long total = (long long)ge.ptheta * ge.nscan;
     const size_t tile = (size_t)ge.ndet * ge.ndet;
+    // object adjoint: LDS overlap-add window over runs of sorted positions (k_adjwin_generic) when the window fits
+    const size_t win_bytes = (size_t)(ge.nprb + 8) * (16 + kBucketPx) * sizeof(c32);
+    bool windowed = flg == 0 && h->use_window && win_bytes + sizeof(RunMeta) + 256 <= 160 * 1024;
+    if (windowed && win_bytes > 48 * 1024 &&
+        hipFuncSetAttribute((const void*)k_adjwin_generic, hipFuncAttributeMaxDynamicSharedMemorySize, (int)win_bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        windowed = false;
+    }
+    if (windowed) {
+        int rc = sort_positions(h, scan, st);
+        if (rc) return rc;
+    }
     for (long long k0 = 0; k0 < total; k0 += h->chunk) {
         const long long k1 = k0 + h->chunk < total ? k0 + h->chunk : total;
-        int rc = launch_lines<M, +1>(h, g + (size_t)k0 * tile, h->scratch, k1 - k0, false, nullptr, st);
+        // windowed: the chunk is a range of the SORTED order, its tiles are gathered through order[]
+        int rc = launch_lines<M, +1>(h, windowed ? g : g + (size_t)k0 * tile, h->scratch, k1 - k0, false, windowed ? h->order + k0 : nullptr, st);
         if (rc) return rc;
         rc = launch_lines<M, +1>(h, h->scratch, h->scratch, k1 - k0, true, nullptr, st);
         if (rc) return rc;
-        if (flg == 0) {
+        if (windowed) {
+            ColArgs ca{};
+            ca.src = h->scratch; ca.dst = f; ca.aux = prb; ca.scan = scan; ca.ge = ge; ca.order = h->order;
+            ca.k_begin = (int)k0; ca.k_end = (int)k1; ca.strip0 = 0; ca.nstrips = (ge.nprb + 15) / 16;
+            const int np = (int)(k1 - k0);
+            int nseg = (h->n_cu * 4 + ca.nstrips - 1) / ca.nstrips;
+            if (nseg < 1) nseg = 1;
+            int seglen = (np + nseg - 1) / nseg;
+            if (seglen < min_seglen()) seglen = min_seglen();
+            if (seglen > kRunMax) seglen = kRunMax;
+            nseg = (np + seglen - 1) / seglen;
+            ProfSpan ps(h, K_COLS_ADJ_OBJ, st);
+            hipLaunchKernelGGL(k_adjwin_generic, dim3((unsigned)(ca.nstrips * nseg)), dim3(256), win_bytes, st, ca, seglen);
+        } else if (flg == 0) {
             const long long npix = (k1 - k0) * ge.nprb * ge.nprb;
             ProfSpan ps(h, K_COLS_ADJ_OBJ, st);
             hipLaunchKernelGGL(k_adj_obj_generic, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, st, f, (const c32*)prb, scan,
