@@ -31,3 +31,23 @@ def test_bench_runs_with_two_ranks():
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
     assert d["cg_iterations_per_s"] > 0 and d["cg_strong_iterations_per_s"] > 0
     assert d["roofline"]["achieved"] > 0
+
+
+def test_bench_runs_on_rccl_with_one_rank():
+    """The RCCL ("nccl") code path of ``bench.py`` -- process group on the GPU, asynchronous object all-reduce between the
+    steps, all-reduced scalars and gradients of the native CG stages -- with ONE rank (``BENCH_FORCE_DIST=1``): what a
+    one-GPU box can load and run of the N > 1 job.  The multi-rank logic is the two-rank gloo test above."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    port = 29900 + (os.getpid() % 90)
+    env = dict(os.environ, BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+               RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
+           "--no-cpu", "--no-cfg3", "--cg-iters", "3", "--raster", "16"]
+    out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["value"] > 0 and d["cg_iterations_per_s"] > 0
