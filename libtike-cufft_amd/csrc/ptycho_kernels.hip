@@ -534,8 +534,10 @@ int project_maxword(ptycho_handle h, int dst_slot, RowFusedArgs& a, hipStream_t 
     return PTYCHO_OK;
 }
 
+// npos_limit > 0: only the first npos_limit positions (natural order = sorted order for whole angles: the sort key is
+// angle major) -- the position correction needs angle 0 only (ptycho.py:399-403)
 template <int N>
-int do_cg_fwd_cols(ptycho_handle h, int slot, const c32* f, const float* scan, const c32* prb, hipStream_t st) {
+int do_cg_fwd_cols(ptycho_handle h, int slot, const c32* f, const float* scan, const c32* prb, hipStream_t st, long long npos_limit = 0) {
     const Geom& ge = h->ge;
     const long long total = (long long)ge.ptheta * ge.nscan;
     int strip0, nstrips;
@@ -548,7 +550,7 @@ int do_cg_fwd_cols(ptycho_handle h, int slot, const c32* f, const float* scan, c
     }
     ColArgs ca{};
     ca.src = f; ca.dst = h->work[slot]; ca.aux = prb; ca.scan = scan; ca.table = h->table; ca.ge = ge;
-    ca.k_begin = 0; ca.k_end = (int)total; ca.strip0 = strip0; ca.nstrips = nstrips;
+    ca.k_begin = 0; ca.k_end = (int)((npos_limit > 0 && npos_limit < total) ? npos_limit : total); ca.strip0 = strip0; ca.nstrips = nstrips;
     if (window) {
         ca.order = h->order;
         if constexpr (WinCfg<N>::fits) rc = launch_gatherwin<N, M_FWD>(h, ca, st);
@@ -1179,9 +1181,9 @@ int ptycho_fft2(ptycho_handle h, void* dst, const void* src, size_t nbatch, int 
 }  // extern "C"
 
 template <int N>
-int do_cg_argmax(ptycho_handle h, int slot, unsigned long long* best, hipStream_t st, bool zeroed = false) {
+int do_cg_argmax(ptycho_handle h, int slot, unsigned long long* best, hipStream_t st, bool zeroed = false, int npos_limit = 0) {
     using CC = ColCfg<N>;
-    const int npos = h->ge.ptheta * h->ge.nscan;
+    const int npos = npos_limit > 0 ? npos_limit : h->ge.ptheta * h->ge.nscan;
     constexpr int nstrips = N / CC::C;
     int ng = (h->n_cu * 8) / nstrips;
     if (ng < 1) ng = 1;
@@ -1226,7 +1228,7 @@ extern "C" int ptycho_cg_argmax(ptycho_handle h, int slot, void* best, void* str
 
 namespace {
 int zoom_impl(ptycho_handle h, const void* image_product, const void* best, const void* vt,
-              const void* lz, int nc, int ups, double upsample_factor, void* shifts, float* scan_add, void* stream);
+              const void* lz, int nc, int ups, double upsample_factor, void* shifts, float* scan_add, void* stream, int npos_limit = 0);
 }
 extern "C" int ptycho_cg_zoom(ptycho_handle h, const void* image_product, const void* best, const void* vt,
                               const void* lz, int nc, int ups, double upsample_factor, void* shifts, void* stream) {
@@ -1235,7 +1237,7 @@ extern "C" int ptycho_cg_zoom(ptycho_handle h, const void* image_product, const 
 namespace {
 // scan_add: scan[0, :] += shifts (ptycho.py:403) by the kernel that finds them (native CG stages)
 int zoom_impl(ptycho_handle h, const void* image_product, const void* best, const void* vt,
-              const void* lz, int nc, int ups, double upsample_factor, void* shifts, float* scan_add, void* stream) {
+              const void* lz, int nc, int ups, double upsample_factor, void* shifts, float* scan_add, void* stream, int npos_limit) {
     int rc = check_handle(h);
     if (rc) return rc;
     if (!image_product) {   // NULL: work slot 2 (see ptycho_cg_cross)
@@ -1248,11 +1250,12 @@ int zoom_impl(ptycho_handle h, const void* image_product, const void* best, cons
     if (N % 16 != 0 || N > 1024) return fail(PTYCHO_ERR_ARG, "zoomed DFT kernel needs ndet %% 16 == 0 and ndet <= 1024");
     if (ups < 1 || ups > nthreads || nc < 0 || nc > kZoomRK || !(upsample_factor >= 1.0))
         return fail(PTYCHO_ERR_ARG, "zoomed DFT window, rank split or upsample factor out of range");
-    const int npos = h->ge.ptheta * h->ge.nscan;
+    const int npos_all = h->ge.ptheta * h->ge.nscan;
+    const int npos = npos_limit > 0 ? npos_limit : npos_all;
     hipStream_t st = (hipStream_t)stream;
     if (!h->zoom_phase) {   // px, py: complex128 [npos][N] each; coarse shifts: float64 [npos][2]
-        HIP_TRY(hipMalloc(&h->zoom_phase, (size_t)npos * N * 2 * sizeof(double2) + (size_t)npos * 2 * sizeof(double)));
-        HIP_TRY(hipMemset(h->zoom_phase, 0, (size_t)npos * N * 2 * sizeof(double2) + (size_t)npos * 2 * sizeof(double)));
+        HIP_TRY(hipMalloc(&h->zoom_phase, (size_t)npos_all * N * 2 * sizeof(double2) + (size_t)npos_all * 2 * sizeof(double)));
+        HIP_TRY(hipMemset(h->zoom_phase, 0, (size_t)npos_all * N * 2 * sizeof(double2) + (size_t)npos_all * 2 * sizeof(double)));
     }
     double2* ppx = (double2*)h->zoom_phase;
     double2* ppy = ppx + (size_t)npos * N;
@@ -1329,7 +1332,8 @@ template <int N>
 int do_cross_dev(ptycho_handle h, const double* gamma_dev, hipStream_t st, int s1_slot) {
     RowFusedArgs a{};
     a.s1 = h->work[s1_slot]; a.s2 = h->work[1]; a.out = h->work[1]; a.ip = h->reg_ip; a.gamma_dev = gamma_dev;
-    a.best_zero = h->reg_best; a.nbest = h->ge.ptheta * h->ge.nscan;   // the arg-max pass that follows finds them cleared
+    a.best_zero = h->reg_best; a.nbest = h->ge.nscan;   // the arg-max pass that follows finds them cleared
+    a.nrows = (long long)h->ge.nscan * N;                // angle 0 only (ptycho.py:399-403: fwd(...)[0], scan[0, :] += shifts)
     h->slot_max_ok[1] = false;
     return do_cg_rows<N, EP_CROSS>(h, a, st);
 }
@@ -1339,7 +1343,12 @@ int cross_dev(ptycho_handle h, const double* gamma_dev, hipStream_t st, int s1_s
 }
 
 int argmax_native(ptycho_handle h, int slot, unsigned long long* best, hipStream_t st) {   // best was cleared by the CROSS stage
-    PTY_DISPATCH(h->ge.ndet, (do_cg_argmax<NN>(h, slot, best, st, true)));
+    PTY_DISPATCH(h->ge.ndet, (do_cg_argmax<NN>(h, slot, best, st, true, h->ge.nscan)));   // angle 0 only
+}
+int fwd_cols_angle0(ptycho_handle h, int slot, const void* f, const void* scan, const void* prb, hipStream_t st) {
+    int rc = ensure_work(h, slot);
+    if (rc) return rc;
+    PTY_DISPATCH(h->ge.ndet, (do_cg_fwd_cols<NN>(h, slot, (const c32*)f, (const float*)scan, (const c32*)prb, st, h->ge.nscan)));
 }
 
 int check_stage(ptycho_handle h, const void* state) {
@@ -1456,8 +1465,7 @@ int ptycho_cg_obj_finish(ptycho_handle h, double* state, int correct_positions, 
     hipStream_t st = (hipStream_t)stream;
     const Geom& ge = h->ge;
     const long long no = (long long)ge.ptheta * ge.nz * ge.n;
-    if (correct_positions) {
-        if (ge.ptheta != 1) return fail(PTYCHO_ERR_ARG, "native position correction needs ptheta = 1");
+    if (correct_positions) {   // angle 0 only, as in the reference (ptycho.py:399-403)
         if (!ones_prb || !vt || !lz) return fail(PTYCHO_ERR_ARG, "null operand");
         const size_t npos = (size_t)ge.nscan;
         if (!h->reg_ip) {
@@ -1468,17 +1476,17 @@ int ptycho_cg_obj_finish(ptycho_handle h, double* state, int correct_positions, 
         // ptycho.py:399-402: tmp1 = fwd(psi, 1), tmp2 = fwd(psi + gamma dpsi, 1) = tmp1 + gamma fwd(dpsi, 1)
         const int s1 = correct_positions == 2 ? 2 : 0;   // 2: ptycho_cg_reg_prepare left the column pass of tmp1 in slot 2
         if (s1 == 0) {
-            rc = ptycho_cg_fwd_cols(h, 0, psi, scan, ones_prb, stream);
+            rc = fwd_cols_angle0(h, 0, psi, scan, ones_prb, st);
             if (rc) return rc;
         }
-        rc = ptycho_cg_fwd_cols(h, 1, dpsi, scan, ones_prb, stream);
+        rc = fwd_cols_angle0(h, 1, dpsi, scan, ones_prb, st);
         if (rc) return rc;
         rc = cross_dev(h, state + PTYCHO_ST_GAMMA_PSI, st, s1);
         if (rc) return rc;
         rc = argmax_native(h, 1, h->reg_best, st);
         if (rc) return rc;
         // the kernel that finds the shifts also adds them to scan[0, :] (ptycho.py:403)
-        rc = zoom_impl(h, h->reg_ip, h->reg_best, vt, lz, nc, ups, upsample_factor, h->reg_shifts, (float*)scan, stream);
+        rc = zoom_impl(h, h->reg_ip, h->reg_best, vt, lz, nc, ups, upsample_factor, h->reg_shifts, (float*)scan, stream, ge.nscan);
         if (rc) return rc;
         h->order_scan = nullptr;   // the positions moved: the next column pass sorts again
     }
@@ -1492,8 +1500,7 @@ int ptycho_cg_reg_prepare(ptycho_handle h, double* state, const void* psi, const
     int rc = check_stage(h, state);
     if (rc) return rc;
     if (!psi || !scan || !ones_prb) return fail(PTYCHO_ERR_ARG, "null operand");
-    if (h->ge.ptheta != 1) return fail(PTYCHO_ERR_ARG, "native position correction needs ptheta = 1");
-    return ptycho_cg_fwd_cols(h, 2, psi, scan, ones_prb, stream);
+    return fwd_cols_angle0(h, 2, psi, scan, ones_prb, (hipStream_t)stream);
 }
 
 int ptycho_cg_prb_grad(ptycho_handle h, double* state, const void* psi, const void* scan, const void* prb,

@@ -683,9 +683,9 @@ class CGPtychoSolver(PtychoHIP):
 
     # -- single-mode gaussian loop, sequenced natively ---------------------------------------
     def _native_ready(self):
-        """The native stage calls cover one probe mode, ptheta = 1 (position correction) and detector
-        sizes the fused zoom kernel accepts."""
-        if not (self.native and self.ptheta == 1 and self.ndet % 16 == 0 and self.ndet <= 1024):
+        """The native stage calls cover one probe mode, any number of angles per call (the position correction touches
+        angle 0 only, like ptycho.py:399-403) and detector sizes the fused zoom kernel accepts."""
+        if not (self.native and self.ndet % 16 == 0 and self.ndet <= 1024):
             return None
         return _zoom_real_factors(self.ndet, 150, 100, self._device)
 
