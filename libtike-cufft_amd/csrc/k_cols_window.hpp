@@ -179,9 +179,6 @@ __global__ __launch_bounds__(ColCfg<N>::NT) void k_cols_adjwin(const ColArgs a, 
             // split kernel: no exchange went through the tile, so the "previous combine is done"
             // barrier sits here, after this position's transform, instead of at the end of the loop
             STAMP(2)      // transform + probe product
-#if defined(PTY_AB) && (PTY_AB & 1)
-            __builtin_amdgcn_sched_barrier(0);   // keep the transform ABOVE the barrier: it overlaps the other waves' combine tail
-#endif
             if (SPLIT) __syncthreads();
             STAMP(3)      // barrier: previous combine done
 #pragma unroll
@@ -388,28 +385,11 @@ __global__ __launch_bounds__(ColCfg<N>::NT) void k_cols_gatherwin(const ColArgs 
     c32 pre_val = zero;
     int pre_slot = -1;
     bool pre_inb = false;
-    // deferred re-anchor (prepare_issue called with defer = true BEFORE the barrier that ends the reads of the
-    // current window: it may start a register load, but must not write the window)
-    int bulk_cnt = 0, bulk_y0 = 0;
-    const c32* bulk_ft = nullptr;
-    auto bulk_fill = [&](const c32* ft, int y0, int cnt) {
-        for (int o = tid; o < cnt; o += NT) {
-            const int Y = y0 + o / WC, col = o % WC;
-            const int X = X0 + col;
-            const bool inb = Y < ge.nz && X >= 0 && X < ge.n;
-            const c32 val = ft[inb ? ((size_t)Y * ge.n + X) : 0];
-            const int ws = (Y % H) * WC + col;
-            win[ws] = inb ? val : zero;
-            if (ws < WC) win[H * WC + ws] = inb ? val : zero;   // mirror of row 0
-        }
-    };
-    auto prepare_issue = [&](int k, int kend, auto defer_c) -> St {
-        constexpr bool defer = decltype(defer_c)::value;
+    auto prepare_issue = [&](int k, int kend) -> St {
         St st;
         st.have = k < kend;
         st.p = 0; st.t = 0; st.Xa = 0; st.q = Pos{0, 0, 0.f, 0.f, false, false};
         pre_slot = -1;
-        bulk_cnt = 0;
         if (!st.have) return st;
         st.p = uni_i(rm.p[k - kb]);
         st.t = st.p / ge.nscan;
@@ -439,20 +419,22 @@ __global__ __launch_bounds__(ColCfg<N>::NT) void k_cols_gatherwin(const ColArgs 
                     pre_inb = inb;                                      // nothing here has to wait for the load
                     pre_slot = (Y % H) * WC + col;
                 }
-            } else if (defer) {
-                bulk_cnt = cnt; bulk_y0 = Yhi; bulk_ft = ft;
             } else {
-                bulk_fill(ft, Yhi, cnt);
+                for (int o = tid; o < cnt; o += NT) {
+                    const int Y = Yhi + o / WC, col = o % WC;
+                    const int X = X0 + col;
+                    const bool inb = Y < ge.nz && X >= 0 && X < ge.n;
+                    const c32 val = ft[inb ? ((size_t)Y * ge.n + X) : 0];
+                    const int ws = (Y % H) * WC + col;
+                    win[ws] = inb ? val : zero;
+                    if (ws < WC) win[H * WC + ws] = inb ? val : zero;   // mirror of row 0
+                }
             }
             Yhi = Rb;
         }
         return st;
     };
     auto prepare_commit = [&]() {
-        if (bulk_cnt > 0) {
-            bulk_fill(bulk_ft, bulk_y0, bulk_cnt);
-            bulk_cnt = 0;
-        }
         if (pre_slot >= 0) {
             const c32 val = pre_inb ? pre_val : zero;
             win[pre_slot] = val;
@@ -460,7 +442,7 @@ __global__ __launch_bounds__(ColCfg<N>::NT) void k_cols_gatherwin(const ColArgs 
         }
     };
     auto prepare = [&](int k, int kend) -> St {
-        St st = prepare_issue(k, kend, std::false_type{});
+        St st = prepare_issue(k, kend);
         prepare_commit();
         return st;
     };
@@ -508,7 +490,7 @@ __global__ __launch_bounds__(ColCfg<N>::NT) void k_cols_gatherwin(const ColArgs 
             } else {
                 __syncthreads();
             }
-            const St cur = prepare_issue(k, ke, std::false_type{});   // same decode as st, plus the window update
+            const St cur = prepare_issue(k, ke);   // same decode as st, plus the window update
             if (SPLIT) {
                 fft.template compute<LAST>(v);
             } else if (P::NSTEP > 1) {
@@ -609,10 +591,10 @@ __global__ __launch_bounds__(ColCfg<N>::NT) void k_cols_gatherwin(const ColArgs 
             for (int s2 = 0; s2 < E; ++s2) asm volatile("" : "+v"(v[s2]));
 #endif
             STAMP(1)      // gather: LDS taps + bilinear weights
-            // split kernel: this thread's share of the rows that slide in for position k + 1 is requested NOW, ahead
-            // of this position's 16 stores -- vector memory operations complete in issue order, so a load issued
-            // behind the stores would wait for all of them to drain to HBM before the window could move on
-            if (SPLIT) nx = prepare_issue(k + 1, ke, std::true_type{});
+            // (Round 3 tried requesting the rows that slide in for position k + 1 HERE, ahead of this position's 16 stores
+            // -- vector memory operations complete in issue order, so the load behind the stores waits for them to drain
+            // -- : the phase stamps moved as expected, the kernel got 6 % slower (0.465 -> 0.495 ms: 112 instead of 68
+            // VGPRs and a worse schedule); profiles/r03/stamps.txt.)
             if (NM > 1) {
 #pragma unroll
                 for (int s2 = 0; s2 < E; ++s2) vbase[s2] = v[s2];
@@ -636,8 +618,9 @@ __global__ __launch_bounds__(ColCfg<N>::NT) void k_cols_gatherwin(const ColArgs 
             STAMP(3)      // store issue
             __syncthreads();   // every bilinear read of position k is done
             STAMP(4)      // barrier
+            nx = prepare_issue(k + 1, ke);
             prepare_commit();
-            STAMP(5)      // window update (LDS store of the rows requested above)
+            STAMP(5)      // window update (global load of the rows that slide in + LDS store)
             __syncthreads();
             STAMP(6)      // barrier
             st = nx;
@@ -658,7 +641,7 @@ __global__ __launch_bounds__(ColCfg<N>::NT) void k_cols_gatherwin(const ColArgs 
             if (P::NSTEP > 1) {
                 fft.template store<0>(v, j0, [&](int i, c32 val) { lds[i * C + c] = val; });
                 __syncthreads();
-                if (MODE == M_FWD && km == 0) nx = prepare_issue(k + 1, ke, std::false_type{});   // window of k is no longer read
+                if (MODE == M_FWD && km == 0) nx = prepare_issue(k + 1, ke);   // window of k is no longer read
                 fft.template load<1>(v, j0, [&](int i) { return lds[i * C + c]; });
                 if (P::NSTEP > 2) {
                     __syncthreads();
@@ -672,7 +655,7 @@ __global__ __launch_bounds__(ColCfg<N>::NT) void k_cols_gatherwin(const ColArgs 
                 fft.template compute<LAST>(v);
             } else if (MODE == M_FWD && km == 0) {
                 __syncthreads();
-                nx = prepare_issue(k + 1, ke, std::false_type{});
+                nx = prepare_issue(k + 1, ke);
             }
             if (MODE == M_FWD) {
                 c32* tile_out = (NM == 1 ? a.dst : a.dstm[km]) + (size_t)st.p * N * N;
