@@ -196,7 +196,7 @@ int ptycho_cg_zoom(ptycho_handle h, const void* image_product, const void* best,
  *                         all-reduce anyway issues it in that gap; ptycho_cg_obj_finish then takes correct_positions = 2
  *   ptycho_cg_obj_finish  i > 0: position correction (:398-403; needs the zoom factors of ptycho_cg_zoom), scan[0] += shifts
  *                         (by the kernel that finds them; the next column pass re-sorts the positions);
- *                         psi += gamma dpsi (:405).  correct_positions: 0 off, 1 on, 2 on with slot 2 prepared
+ *                         psi += gamma dpsi (:405).  correct_positions: 0 off, 1 on, 2 on with slot 2 prepared, 3 on with slots 2 and 3 prepared
  *   ptycho_cg_prb_grad    slot 0 <- column pass of fwd(psi, probe); slot 1 <- projected residual (:421-430);
  *                         gprb <- adj_probe (raw).                   all-reduce: gprb
  *   ptycho_cg_prb_dir     gprb <- gprb / max|psi|^2 / nscan_total * nmodes (:431); Dai-Yuan dprb (:437-448);
@@ -218,6 +218,13 @@ enum {
 };
 int ptycho_cg_obj_begin(ptycho_handle h, double* state, const void* psi, const void* scan, const void* prb,
                         const void* data, void* stream);
+/* obj_begin2 / obj_dir2: as obj_begin / obj_dir; with ones_prb != NULL the operands of the position correction ride along --
+ * slot 2 <- column pass of fwd(psi, 1), slot 3 <- column pass of fwd(dpsi, 1) -- in the same launches, which gather the
+ * object patch once for both probes; ptycho_cg_obj_finish then takes correct_positions = 3 (both prepared). */
+int ptycho_cg_obj_begin2(ptycho_handle h, double* state, const void* psi, const void* scan, const void* prb,
+                         const void* ones_prb, const void* data, void* stream);
+int ptycho_cg_obj_dir2(ptycho_handle h, double* state, int first, const void* scan, const void* prb, const void* ones_prb,
+                       const void* data, void* grad, void* grad0, void* dpsi, void* stream);
 int ptycho_cg_obj_grad(ptycho_handle h, double* state, const void* scan, void* prb, const void* data, void* grad,
                        void* stream);
 int ptycho_cg_obj_dir(ptycho_handle h, double* state, int first, const void* scan, const void* prb, const void* data,

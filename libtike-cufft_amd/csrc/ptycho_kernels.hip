@@ -1329,17 +1329,37 @@ int ls_pass(ptycho_handle h, const void* data, int use_ab, double* state, hipStr
 constexpr int kLsNext[8] = {0, 1, 2, 4, 0, kLsGroupsMax, 2, 5};
 
 template <int N>
-int do_cross_dev(ptycho_handle h, const double* gamma_dev, hipStream_t st, int s1_slot) {
+int do_cross_dev(ptycho_handle h, const double* gamma_dev, hipStream_t st, int s1_slot, int s2_slot) {
     RowFusedArgs a{};
-    a.s1 = h->work[s1_slot]; a.s2 = h->work[1]; a.out = h->work[1]; a.ip = h->reg_ip; a.gamma_dev = gamma_dev;
+    a.s1 = h->work[s1_slot]; a.s2 = h->work[s2_slot]; a.out = h->work[s2_slot]; a.ip = h->reg_ip; a.gamma_dev = gamma_dev;
     a.best_zero = h->reg_best; a.nbest = h->ge.nscan;   // the arg-max pass that follows finds them cleared
     a.nrows = (long long)h->ge.nscan * N;                // angle 0 only (ptycho.py:399-403: fwd(...)[0], scan[0, :] += shifts)
-    h->slot_max_ok[1] = false;
+    h->slot_max_ok[s2_slot] = false;
     return do_cg_rows<N, EP_CROSS>(h, a, st);
 }
-int cross_dev(ptycho_handle h, const double* gamma_dev, hipStream_t st, int s1_slot = 0) {
-    if (!slot_ready(h, s1_slot) || !slot_ready(h, 1)) return fail(PTYCHO_ERR_ARG, "work slot is empty");
-    PTY_DISPATCH(h->ge.ndet, (do_cross_dev<NN>(h, gamma_dev, st, s1_slot)));
+int cross_dev(ptycho_handle h, const double* gamma_dev, hipStream_t st, int s1_slot = 0, int s2_slot = 1) {
+    if (!slot_ready(h, s1_slot) || !slot_ready(h, s2_slot)) return fail(PTYCHO_ERR_ARG, "work slot is empty");
+    PTY_DISPATCH(h->ge.ndet, (do_cross_dev<NN>(h, gamma_dev, st, s1_slot, s2_slot)));
+}
+
+template <int N>
+int do_cg_fwd_cols_modes(ptycho_handle h, int nmodes, c32* const* dst, const c32* f, const float* scan, const c32* const* prbs,
+                         int k_begin, int k_end, hipStream_t st, const double* skip);   // defined below
+
+// Column passes of fwd(obj, probe) -> slot_p and fwd(obj, ones) -> slot_o in ONE launch that gathers the object patch
+// once per position (k_cols_gatherwin<..., NM = 2>): the position correction's operands (ptycho.py:399-402) ride along
+// with the passes the object step makes anyway.  Falls back to two passes where the shared-gather kernel does not apply.
+template <int N>
+int do_fwd_cols_pair(ptycho_handle h, int slot_p, int slot_o, const c32* f, const float* scan, const c32* prb, const c32* ones, hipStream_t st) {
+    c32* dst[2] = {h->work[slot_p], h->work[slot_o]};
+    const c32* pr[2] = {prb, ones};
+    return do_cg_fwd_cols_modes<N>(h, 2, dst, f, scan, pr, 0, h->ge.ptheta * h->ge.nscan, st, nullptr);
+}
+int fwd_cols_pair(ptycho_handle h, int slot_p, int slot_o, const void* f, const void* scan, const void* prb, const void* ones, hipStream_t st) {
+    int rc = ensure_work(h, slot_p);
+    if (!rc) rc = ensure_work(h, slot_o);
+    if (rc) return rc;
+    PTY_DISPATCH(h->ge.ndet, (do_fwd_cols_pair<NN>(h, slot_p, slot_o, (const c32*)f, (const float*)scan, (const c32*)prb, (const c32*)ones, st)));
 }
 
 int argmax_native(ptycho_handle h, int slot, unsigned long long* best, hipStream_t st) {   // best was cleared by the CROSS stage
@@ -1382,17 +1402,22 @@ int adj_cols_native(ptycho_handle h, int slot, void* f, const void* scan, void* 
 
 extern "C" {
 
-int ptycho_cg_obj_begin(ptycho_handle h, double* state, const void* psi, const void* scan, const void* prb,
-                        const void* data, void* stream) {
+int ptycho_cg_obj_begin2(ptycho_handle h, double* state, const void* psi, const void* scan, const void* prb,
+                         const void* ones_prb, const void* data, void* stream) {
     int rc = check_stage(h, state);
     if (rc) return rc;
     if (!psi || !scan || !prb || !data) return fail(PTYCHO_ERR_ARG, "null operand");
     hipStream_t st = (hipStream_t)stream;
     h->native_order = 1;   // the native loop keeps track of scan itself (ptycho_cg_obj_finish invalidates the order)
     h->det_pending = false;
-    rc = ptycho_cg_fwd_cols(h, 0, psi, scan, prb, stream);
+    if (ones_prb) rc = fwd_cols_pair(h, 0, 2, psi, scan, prb, ones_prb, st);     // + slot 2 <- column pass of fwd(psi, 1)
+    else rc = ptycho_cg_fwd_cols(h, 0, psi, scan, prb, stream);
     if (rc) return rc;
     return stats_native(h, 0, data, state + PTYCHO_ST_A, st);
+}
+int ptycho_cg_obj_begin(ptycho_handle h, double* state, const void* psi, const void* scan, const void* prb,
+                        const void* data, void* stream) {
+    return ptycho_cg_obj_begin2(h, state, psi, scan, prb, nullptr, data, stream);
 }
 
 int ptycho_cg_obj_grad(ptycho_handle h, double* state, const void* scan, void* prb, const void* data, void* grad,
@@ -1417,6 +1442,10 @@ int ptycho_cg_obj_grad(ptycho_handle h, double* state, const void* scan, void* p
 
 int ptycho_cg_obj_dir(ptycho_handle h, double* state, int first, const void* scan, const void* prb, const void* data,
                       void* grad, void* grad0, void* dpsi, void* stream) {
+    return ptycho_cg_obj_dir2(h, state, first, scan, prb, nullptr, data, grad, grad0, dpsi, stream);
+}
+int ptycho_cg_obj_dir2(ptycho_handle h, double* state, int first, const void* scan, const void* prb, const void* ones_prb,
+                       const void* data, void* grad, void* grad0, void* dpsi, void* stream) {
     int rc = check_stage(h, state);
     if (rc) return rc;
     if (!scan || !prb || !data || !grad || !grad0 || !dpsi) return fail(PTYCHO_ERR_ARG, "null operand");
@@ -1433,7 +1462,8 @@ int ptycho_cg_obj_dir(ptycho_handle h, double* state, int first, const void* sca
     h->det_pending = false;
     hipLaunchKernelGGL(k_cg_dy_update, dim3(small_grid(h, no)), dim3(256), 0, st, (c32*)dpsi, (c32*)grad0, (const c32*)grad, no,
                        (const double*)(state + PTYCHO_ST_DY_OBJ), first, state, 0);
-    rc = ptycho_cg_fwd_cols(h, 1, dpsi, scan, prb, stream);
+    if (ones_prb) rc = fwd_cols_pair(h, 1, 3, dpsi, scan, prb, ones_prb, st);    // + slot 3 <- column pass of fwd(dpsi, 1)
+    else rc = ptycho_cg_fwd_cols(h, 1, dpsi, scan, prb, stream);
     if (rc) return rc;
     return ls_pass(h, data, 1, state, st, 0, h->ls_fused_decide ? kLsNext[1] : -1);
 }
@@ -1474,16 +1504,20 @@ int ptycho_cg_obj_finish(ptycho_handle h, double* state, int correct_positions, 
             HIP_TRY(hipMalloc((void**)&h->reg_shifts, npos * 2 * sizeof(double)));
         }
         // ptycho.py:399-402: tmp1 = fwd(psi, 1), tmp2 = fwd(psi + gamma dpsi, 1) = tmp1 + gamma fwd(dpsi, 1)
-        const int s1 = correct_positions == 2 ? 2 : 0;   // 2: ptycho_cg_reg_prepare left the column pass of tmp1 in slot 2
+        // 2: ptycho_cg_reg_prepare (or ptycho_cg_obj_begin2) left the column pass of tmp1 in slot 2;
+        // 3: and ptycho_cg_obj_dir2 the column pass of fwd(dpsi, 1) in slot 3
+        const int s1 = correct_positions >= 2 ? 2 : 0, s2 = correct_positions == 3 ? 3 : 1;
         if (s1 == 0) {
             rc = fwd_cols_angle0(h, 0, psi, scan, ones_prb, st);
             if (rc) return rc;
         }
-        rc = fwd_cols_angle0(h, 1, dpsi, scan, ones_prb, st);
+        if (s2 == 1) {
+            rc = fwd_cols_angle0(h, 1, dpsi, scan, ones_prb, st);
+            if (rc) return rc;
+        }
+        rc = cross_dev(h, state + PTYCHO_ST_GAMMA_PSI, st, s1, s2);
         if (rc) return rc;
-        rc = cross_dev(h, state + PTYCHO_ST_GAMMA_PSI, st, s1);
-        if (rc) return rc;
-        rc = argmax_native(h, 1, h->reg_best, st);
+        rc = argmax_native(h, s2, h->reg_best, st);
         if (rc) return rc;
         // the kernel that finds the shifts also adds them to scan[0, :] (ptycho.py:403)
         rc = zoom_impl(h, h->reg_ip, h->reg_best, vt, lz, nc, ups, upsample_factor, h->reg_shifts, (float*)scan, stream, ge.nscan);
@@ -1588,7 +1622,7 @@ int launch_gatherwin_modes(ptycho_handle h, ColArgs a, hipStream_t st) {
 
 template <int N>
 int do_cg_fwd_cols_modes(ptycho_handle h, int nmodes, c32* const* dst, const c32* f, const float* scan, const c32* const* prbs,
-                         int k_begin, int k_end, hipStream_t st, const double* skip = nullptr) {
+                         int k_begin, int k_end, hipStream_t st, const double* skip) {
     const Geom& ge = h->ge;
     int strip0, nstrips;
     strip_range<N>(ge, strip0, nstrips);

@@ -25,7 +25,7 @@ SYMBOLS = ("ptycho_create", "ptycho_free", "ptycho_destroy", "ptycho_get",
            "ptycho_cg_reg_prepare",
            "ptycho_cg_obj_finish", "ptycho_cg_prb_grad", "ptycho_cg_prb_dir", "ptycho_cg_prb_finish",
            "ptycho_cg_ls_begin", "ptycho_cg_ls_obj_chunk", "ptycho_cg_ls_prb_pass", "ptycho_cg_ls_decide",
-           "ptycho_cg_cross_dev",
+           "ptycho_cg_cross_dev", "ptycho_cg_obj_begin2", "ptycho_cg_obj_dir2",
            "ptycho_last_error", "ptycho_version")
 
 if not os.path.exists(LIB_PATH):
@@ -82,6 +82,8 @@ cg_ls_obj_chunk = _sig("ptycho_cg_ls_obj_chunk", _i, _vp, _vp, _i, _vp, _vp, cty
 cg_ls_prb_pass = _sig("ptycho_cg_ls_prb_pass", _i, _vp, _vp, _i, _vp, _vp, _vp)
 cg_ls_decide = _sig("ptycho_cg_ls_decide", _i, _vp, _vp, _i, _i, _vp)
 cg_cross_dev = _sig("ptycho_cg_cross_dev", _i, _vp, _i, _i, _vp, _vp, _vp)
+cg_obj_begin2 = _sig("ptycho_cg_obj_begin2", _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp)
+cg_obj_dir2 = _sig("ptycho_cg_obj_dir2", _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp)
 #: word offsets of the device-resident CG state (enum PTYCHO_ST_* in include/ptycho_hip.h)
 ST_A, ST_B, ST_COST, ST_COST2 = 0, 1, 2, 3
 ST_GAMMA_PSI, ST_GAMMA_PRB, ST_LS_FAILED, ST_HINT, ST_COSTS, ST_WORDS = 12, 13, 19, 20, 24, 160

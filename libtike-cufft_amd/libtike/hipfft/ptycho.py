@@ -571,6 +571,7 @@ class CGPtychoSolver(PtychoHIP):
         self.native = True     # single-mode loop sequenced by the native stage calls (no host round trips)
         self._nscan_all = None
         self.reproducible = True  # fused CG loops use the deterministic adjoints (same trajectory every run)
+        self.share_ones = True    # native loop: the position correction's column passes share the object step's patch gathers
         self.ls_two_pass = None  # native line search with few collectives (<= 16, 32, 80 step lengths); None: with a group only
 
     # -- distributed glue ----------------------------------------------------
@@ -741,7 +742,11 @@ class CGPtychoSolver(PtychoHIP):
             """One CG iteration as a fixed sequence of launches on the current stream (no host decisions)."""
             S = _stream()
             # 1) object step (ptycho.py:325-405)
-            nat.check(nat.cg_obj_begin(h, sp, _ptr(psi), _ptr(scan), _ptr(probe), _ptr(data), S))
+            # with the position correction on, its two operands (column passes of fwd(psi, 1) and fwd(dpsi, 1)) ride
+            # along with the object step's own column passes: one patch gather per position serves both probes
+            share = bool(correct) and self.share_ones and self.ndet <= 512 and self.ptheta == 1
+            op = _ptr(ones) if share else None
+            nat.check(nat.cg_obj_begin2(h, sp, _ptr(psi), _ptr(scan), _ptr(probe), op, _ptr(data), S))
             if dist_on:
                 self._allreduce(st[nat.ST_A:nat.ST_A + 2])
             nat.check(nat.cg_obj_grad(h, sp, _ptr(scan), _ptr(probe), _ptr(data), _ptr(grad), S))
@@ -750,12 +755,14 @@ class CGPtychoSolver(PtychoHIP):
                 # correction (column pass of fwd(psi, 1): depends on psi and scan only) is computed under it
                 import torch.distributed as dist
                 work = dist.all_reduce(torch.view_as_real(grad), group=self.group, async_op=True)
-                if correct:
+                if correct and not share:
                     nat.check(nat.cg_reg_prepare(h, sp, _ptr(psi), _ptr(scan), _ptr(ones), S))
                     correct = 2
                 work.wait()
-            nat.check(nat.cg_obj_dir(h, sp, first, _ptr(scan), _ptr(probe), _ptr(data), _ptr(grad),
-                                     _ptr(grad0), _ptr(dpsi), S))
+            nat.check(nat.cg_obj_dir2(h, sp, first, _ptr(scan), _ptr(probe), op, _ptr(data), _ptr(grad),
+                                      _ptr(grad0), _ptr(dpsi), S))
+            if share:
+                correct = 3
             line_search(0, 1, S)
             nat.check(nat.cg_obj_finish(h, sp, correct, _ptr(psi), _ptr(dpsi), _ptr(scan), _ptr(ones),
                                         _ptr(vt), _ptr(lz), nc, 150, 100.0, S))
