@@ -52,6 +52,7 @@ def parse():
     ap.add_argument("--no-cg", action="store_true")
     ap.add_argument("--no-cfg3", action="store_true", help="skip the configs[2] secondary figures (4096 x 512^2, 4 modes)")
     ap.add_argument("--cfg3-iters", type=int, default=6)
+    ap.add_argument("--no-shard", action="store_true", help="skip the configs[3] shard and configs[4] angle-streaming secondary figures")
     return ap.parse_args()
 
 
@@ -103,6 +104,85 @@ def cfg3_figures(pt, syn, dev, iters):
             "cfg3_device_gib_in_use": (free0 - free1) / 2.0 ** 30,
             "cfg3_note": "CG: 4 modes, no probe recovery, position correction on; memory = device memory taken between "
                          "solver creation and the end of the run (work slots, scratch, intensity, registration, data 4 GiB)"}
+
+
+def shard_and_stream_figures(pt, syn, dev, iters=6):
+    """Secondary figures for the two multi-GPU entries of BASELINE.json, as far as ONE GPU can measure them:
+    configs[3]: one rank's share of the 262144-position job = 32768 positions x 256^2 (a 64 x 512 band of the raster, 16 GiB
+    farplane): fwd+adj pair and CG iterations/s (the 8-GPU job adds one object all-reduce per step);
+    configs[4]: angles streamed through run_batch (NumPy in / out, pinned double buffer + copy stream): seconds per additional
+    angle of 4096 x 256^2 with 20 CG iterations each, against the same solves on resident data."""
+    out = {}
+    R1, R2, step = 64, 512, 8
+    nz, n = syn.object_size_for(R1, R2, step, 256)
+    rng = np.random.default_rng(31)
+    psi = torch.as_tensor(syn.random_object(nz, n, rng), device=dev)
+    scan = torch.as_tensor(syn.raster_scan(R1, R2, step, rng), device=dev)
+    prb_h = syn.gaussian_probe(256)
+    prb = torch.as_tensor((prb_h * np.exp(2j * np.pi * rng.random(prb_h.shape[-2:]))).astype(np.complex64), device=dev)
+    npos = R1 * R2
+    slv = pt.CGPtychoSolver(npos, 256, 256, 1, nz, n)
+    slv.verbose = False
+    g = torch.empty((1, npos, 256, 256), dtype=torch.complex64, device=dev)
+    o = torch.empty_like(psi)
+    for _ in range(2):
+        slv.adj(slv.fwd(psi, scan, prb, out=g), scan, prb, out=o)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        slv.adj(slv.fwd(psi, scan, prb, out=g), scan, prb, out=o)
+    torch.cuda.synchronize()
+    pair_ms = (time.perf_counter() - t0) / 5 * 1e3
+    data = torch.empty((1, npos, 256, 256), dtype=torch.float32, device=dev)
+    for i in range(0, npos, 4096):
+        data[:, i:i + 4096] = torch.abs(g[:, i:i + 4096]) ** 2
+    del g
+    torch.cuda.empty_cache()
+    slv.run(data, torch.ones_like(psi), scan.clone(), prb[:, None].clone(), piter=2)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    slv.run(data, torch.ones_like(psi), scan.clone(), prb[:, None].clone(), piter=iters)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / iters
+    slv.free()
+    del data, psi, scan
+    torch.cuda.empty_cache()
+    pair_bytes = 2.0 * (8.0 * npos * 256 * 256 + 8.0 * nz * n + 8.0 * 256 * 256 + 8.0 * npos)
+    out.update({"cfg4_shard_workload": "one GPU's share of configs[3]: 32768 positions x (256x256), object %dx%d (phase-screened probe)" % (nz, n),
+                "cfg4_shard_pair_ms": pair_ms, "cfg4_shard_patterns_per_s": npos / (pair_ms * 1e-3),
+                "cfg4_shard_roofline_frac": pair_bytes / (pair_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "cfg4_shard_cg_it_s": 1.0 / dt, "cfg4_shard_cg_ms_per_iteration": dt * 1e3})
+    # configs[4]: angle streaming
+    NA, PIT = 6, 20
+    p = syn.make_problem(64, 64, 8, 256, 256, seed=1234, nz=768, n=768)
+    prbs = (p["probe"] * np.exp(2j * np.pi * np.random.default_rng(5).random((256, 256)))).astype(np.complex64)
+    s2 = pt.CGPtychoSolver(4096, 256, 256, 1, 768, 768)
+    s2.verbose = False
+    D = lambda x: torch.as_tensor(np.ascontiguousarray(x), device=dev)
+    data1 = (torch.abs(s2.fwd(D(p["psi"]), D(p["scan"]), D(prbs))) ** 2).cpu().numpy()
+    data = np.repeat(data1, NA, axis=0)
+    scan = np.repeat(p["scan"], NA, axis=0)
+    psi0 = np.ones((NA,) + p["psi"].shape[1:], np.complex64)
+    prb4 = np.repeat(prbs[:, None], NA, axis=0)
+    d_gpu, s_gpu, q_gpu = D(data1), D(p["scan"]), D(prbs[:, None].copy())
+    s2.run(d_gpu, D(psi0[:1].copy()), s_gpu.clone(), q_gpu.clone(), piter=PIT)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        s2.run(d_gpu, D(psi0[:1].copy()), s_gpu.clone(), q_gpu.clone(), piter=PIT)
+    torch.cuda.synchronize()
+    t_res = (time.perf_counter() - t0) / 3
+    t0 = time.perf_counter()
+    s2.run_batch(data[:NA // 2], psi0[:NA // 2], scan[:NA // 2], prb4[:NA // 2], piter=PIT)
+    t_half = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    s2.run_batch(data, psi0, scan, prb4, piter=PIT)
+    t_full = time.perf_counter() - t0
+    s2.free()
+    out.update({"cfg5_workload": "angles of 4096 positions x (256x256) streamed through run_batch (NumPy in / out, 1 GiB of data per angle), %d CG iterations per angle" % PIT,
+                "cfg5_s_per_angle_streamed": (t_full - t_half) / (NA - NA // 2), "cfg5_s_per_angle_resident": t_res,
+                "cfg5_note": "marginal cost per additional angle (set-up of the pinned buffers excluded); 180 angles over 8 GPUs = 22.5 angles per GPU, no collective"})
+    return out
 
 
 def generic_figures(pt, syn, dev):
@@ -490,6 +570,12 @@ def main():
             out.update(generic_figures(pt, syn, dev))
         except Exception as e:
             print("generic-size figures failed: %r" % (e,), file=sys.stderr)
+        if not args.no_shard:
+            try:
+                torch.cuda.empty_cache()
+                out.update(shard_and_stream_figures(pt, syn, dev))
+            except Exception as e:
+                print("configs[3] shard / configs[4] streaming figures failed: %r" % (e,), file=sys.stderr)
     if dist:
         dist.barrier()
         dist.destroy_process_group()
