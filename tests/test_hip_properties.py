@@ -84,3 +84,43 @@ def test_poisson_model_is_broken_like_the_reference(pt):
         with pytest.raises(UnboundLocalError):
             slv.run(z(1, 4, 16, 16, dt=torch.float32), z(1, 40, 40), z(1, 4, 2, dt=torch.float32),
                     z(1, 1, 16, 16), piter=1, model="poisson")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("npos,ndet", [(37, 64), (300, 128), (2048, 256)])
+def test_cross_workgroup_sums_are_exact_and_repeatable(npos, ndet):
+    """The fixed-order fold across workgroups (a, b of ptycho.py:342-343 through ``ptycho_cg_stats``): equal to a float64
+    torch reduction of the same farplane to 1e-6, and the same bits on every one of 100 repeats with other kernels in
+    between (a stale partial row or a lost ticket would show as a different sum)."""
+    import ctypes
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import libtike.hipfft as pt
+    from libtike.hipfft import _native as nat, synthetic as syn
+    from libtike.hipfft.ptycho import _ptr, _stream
+    R = int(np.ceil(np.sqrt(npos)))
+    p = syn.make_problem(R, R, 3, ndet, ndet, seed=npos)
+    scan = np.ascontiguousarray(p["scan"][:, :npos])
+    rng = np.random.default_rng(npos)
+    prb = (p["probe"] * np.exp(2j * np.pi * rng.random((ndet, ndet)))).astype(np.complex64)
+    dev = lambda x: torch.as_tensor(np.ascontiguousarray(x), device="cuda")
+    with pt.CGPtychoSolver(npos, ndet, ndet, 1, p["nz"], p["n"]) as slv:
+        psi, scan_d, prb_d = dev(p["psi"]), dev(scan), dev(prb)
+        g = slv.fwd(psi, scan_d, prb_d)
+        inten = (g.real.double() ** 2 + g.imag.double() ** 2)
+        data = (torch.abs(g) ** 2 * (0.5 + torch.rand(g.shape, device="cuda"))).float().contiguous()
+        want = torch.stack((torch.sqrt(inten.float().double() * data.double()).sum(), inten.sum())).cpu().numpy()
+        slv._note_scan(scan_d)
+        nat.check(nat.cg_fwd_cols(slv._h, 0, _ptr(psi), _ptr(scan_d), _ptr(prb_d), _stream()))
+        sums = torch.zeros(2, dtype=torch.float64, device="cuda")
+        seen = set()
+        for rep in range(100):
+            sums.zero_()
+            nat.check(nat.cg_stats(slv._h, 0, _ptr(data), _ptr(sums), _stream()))
+            if rep % 3 == 0:     # other work in between: the row pass of an operator call uses the same CUs
+                slv.fwd(psi, scan_d, prb_d, out=g)
+            seen.add(tuple(sums.cpu().numpy().tolist()))
+        assert len(seen) == 1, seen
+        got = np.array(next(iter(seen)))
+        assert np.all(np.abs(got - want) <= 2e-6 * np.abs(want)), (got, want)
