@@ -323,6 +323,8 @@ __global__ __launch_bounds__(ColCfg<N>::NT) void k_cols_gatherwin(const ColArgs 
 
     // NM > 1: the inter-step twiddles are re-read from an LDS copy of the table before each step (init_step) instead
     // of living in up to 64 VGPRs next to the shared patch values and the probe strip in flight
+    // (Round 3: for ndet <= 256 and two modes the registers could hold both probe strips and the twiddles; hoisting them
+    // out of the position loop measured SLOWER -- 1.24 -> 1.49 ms per pass at 4096 x 256^2 -- so every NM > 1 takes this path.)
     __shared__ c32 wtab[NM > 1 ? N : 1];
     F fft;
     if (NM == 1) fft.init(j0, a.table);

@@ -658,7 +658,7 @@ __global__ __launch_bounds__(256, (fused_min_waves<N, EP>())) void k_rows_fused(
     }
     }   // grp
     // ---- totals over the workgroups in a fixed order; the last workgroup to arrive publishes them ----------
-    int nv = LS ? ngroups * (kMaxCand + 1) : NACC, nmax = 0;
+    int nv = LS ? (ngroups - 1) * (kMaxCand + 1) + ncand + 1 : NACC, nmax = 0;   // line search: costs[.. ncand] of the last group, no further
     if (EP == EP_PROJECT && a.maxword) {   // max |out| rides along as one more value (folded with max)
         float m = vmax2;
 #pragma unroll
