@@ -173,7 +173,15 @@ int alloc_scratch(ptycho_handle h) {
 int sort_positions(ptycho_handle h, const float* scan, hipStream_t st);   // ptycho_sort.hip-style helper below
 
 // shortest run of sorted positions a windowed column workgroup takes (each run pays one window fill)
-static int min_seglen() { static const int v = exp_env("PTYCHO_HIP_MINSEG", 16); return v < 1 ? 1 : v; }   // 512 positions x 256^2 CG: 8 -> 1.44, 16 -> 1.36, 24 -> 1.51 ms per iteration
+// 512 positions x 256^2 CG: 8 -> 1.44, 16 -> 1.36, 24 -> 1.51 ms per iteration.  Tiny problems (fewer than one workgroup per CU at
+// runs of 16) take shorter runs, down to 4: a workgroup's positions are processed one after the other (~5 us each)
+static int min_seglen(int np = 1 << 30, int nstrips = 1, int n_cu = 256) {
+    static const int v = exp_env("PTYCHO_HIP_MINSEG", 16);
+    int m = v < 1 ? 1 : v;
+    const long long fill = (long long)np * nstrips / (n_cu > 0 ? n_cu : 1);   // run length that gives one workgroup per CU
+    if (fill < m) m = fill < 4 ? 4 : (int)fill;
+    return m;
+}
 
 template <int N, int DIR, int MODE>
 int launch_cols(ptycho_handle h, ColArgs a, hipStream_t st) {
@@ -204,7 +212,7 @@ int launch_adjwin(ptycho_handle h, ColArgs a, hipStream_t st, int wg_target = 0)
     int nseg = (wg_target + a.nstrips - 1) / a.nstrips;
     if (nseg < 1) nseg = 1;
     int seglen = (np + nseg - 1) / nseg;
-    if (seglen < min_seglen()) seglen = min_seglen();
+    if (seglen < min_seglen(np, a.nstrips, h->n_cu)) seglen = min_seglen(np, a.nstrips, h->n_cu);
     if (seglen > kRunMax) seglen = kRunMax;
     nseg = (np + seglen - 1) / seglen;
     static const int nt_mode_a = exp_env("PTYCHO_HIP_NT", 0);
@@ -229,7 +237,7 @@ int launch_gatherwin(ptycho_handle h, ColArgs a, hipStream_t st, int wg_target =
     int nseg = (wg_target + a.nstrips - 1) / a.nstrips;
     if (nseg < 1) nseg = 1;
     int seglen = (np + nseg - 1) / nseg;
-    if (seglen < min_seglen()) seglen = min_seglen();
+    if (seglen < min_seglen(np, a.nstrips, h->n_cu)) seglen = min_seglen(np, a.nstrips, h->n_cu);
     if (seglen > kRunMax) seglen = kRunMax;
     nseg = (np + seglen - 1) / seglen;
 #ifdef PTYCHO_EXPERIMENTS
@@ -699,7 +707,7 @@ int do_adj_generic(ptycho_handle h, c32* f, const c32* g, const float* scan, c32
             int nseg = (h->n_cu * 4 + ca.nstrips - 1) / ca.nstrips;
             if (nseg < 1) nseg = 1;
             int seglen = (np + nseg - 1) / nseg;
-            if (seglen < min_seglen()) seglen = min_seglen();
+            if (seglen < min_seglen(np, ca.nstrips, h->n_cu)) seglen = min_seglen(np, ca.nstrips, h->n_cu);
             if (seglen > kRunMax) seglen = kRunMax;
             nseg = (np + seglen - 1) / seglen;
             ProfSpan ps(h, K_COLS_ADJ_OBJ, st);
@@ -1608,7 +1616,7 @@ int launch_gatherwin_modes(ptycho_handle h, ColArgs a, hipStream_t st) {
     int nseg = (h->n_cu * 4 + a.nstrips - 1) / a.nstrips;
     if (nseg < 1) nseg = 1;
     int seglen = (np + nseg - 1) / nseg;
-    if (seglen < min_seglen()) seglen = min_seglen();
+    if (seglen < min_seglen(np, a.nstrips, h->n_cu)) seglen = min_seglen(np, a.nstrips, h->n_cu);
     if (seglen > kRunMax) seglen = kRunMax;
     nseg = (np + seglen - 1) / seglen;
     a.nt = 0;
