@@ -67,8 +67,6 @@ def cfg3_figures(pt, syn, dev, iters):
     scan = torch.as_tensor(syn.raster_scan(R, R, step, rng), device=dev)
     modes = torch.as_tensor(syn.hermite_modes(ndet, M), device=dev)
     torch.cuda.synchronize()
-    torch.cuda.reset_peak_memory_stats()
-    free0, _ = torch.cuda.mem_get_info()
     slv = pt.CGPtychoSolver(R * R, ndet, ndet, 1, nz, n)
     slv.verbose = False
     prb0 = modes[:, 0].contiguous()
@@ -87,7 +85,10 @@ def cfg3_figures(pt, syn, dev, iters):
         g = slv.fwd(psi, scan, modes[:, k].contiguous())
         data += torch.abs(g) ** 2
     del g
+    slv.release_scratch()           # the adjoint's intermediate of the pair above: the CG loop never uses it
     torch.cuda.empty_cache()
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()      # from here on: what the solver takes next to the caller's data
     slv.run(data, torch.ones_like(psi), scan.clone(), modes.clone(), piter=2)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -102,8 +103,8 @@ def cfg3_figures(pt, syn, dev, iters):
             "cfg3_roofline_frac": pair_bytes / (pair_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
             "cfg3_cg_it_s": 1.0 / dt, "cfg3_cg_ms_per_iteration": dt * 1e3, "cfg3_cg_iters_timed": iters,
             "cfg3_device_gib_in_use": (free0 - free1) / 2.0 ** 30,
-            "cfg3_note": "CG: 4 modes, no probe recovery, position correction on; memory = device memory taken between "
-                         "solver creation and the end of the run (work slots, scratch, intensity, registration, data 4 GiB)"}
+            "cfg3_note": "CG: 4 modes, no probe recovery, position correction on; memory = device memory the solver takes during "
+                         "the run next to the caller's 4 GiB of data (M + 1 = 5 work slots of 8 GiB, summed intensity 4 GiB, registration)"}
 
 
 def shard_and_stream_figures(pt, syn, dev, iters=6):

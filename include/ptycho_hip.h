@@ -273,6 +273,7 @@ int ptycho_cg_cross_dev(ptycho_handle h, int slot1, int slot2, const double* gam
  * ndet <= 512; default 0: float atomics, as kernels.cu:73-80,92-93);
  * "compact_modes" (M = number of probe modes: compact slot layout + chunk-major position order, see above; 0 = slot pairs);
  * "defer_finish", "ls_fused_decide" (native CG stages on one GPU, see above; default 0);
+ * "release_scratch" (any value: frees the adjoint's intermediate, which the fused CG stages never use; ptycho_adj re-allocates it);
  * "trust_order" is the CALLER's: the native CG stages track the scan buffer themselves and do not touch it.
  * Experiments build only (make experiments, -DPTYCHO_EXPERIMENTS; the shipped library rejects / ignores them):
  * "fused" (ndet = 256: forward operator as ONE launch that keeps the column<->row intermediate on the CU,

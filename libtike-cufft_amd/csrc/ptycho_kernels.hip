@@ -989,6 +989,11 @@ int ptycho_set_option(ptycho_handle h, const char* name, long long value) {
         return fail(PTYCHO_ERR_ARG, "option fused: the single-launch forward is an experiment (measured slower, DESIGN.md); build with -DPTYCHO_EXPERIMENTS");
 #endif
     }
+    if (std::strcmp(name, "release_scratch") == 0) {   // give back the adjoint's intermediate (<= 4 GiB; the next ptycho_adj allocates it again)
+        HIP_TRY(hipDeviceSynchronize());
+        if (h->scratch) { HIP_TRY(hipFree(h->scratch)); h->scratch = nullptr; }
+        return PTYCHO_OK;
+    }
     if (std::strcmp(name, "defer_finish") == 0) {
         h->defer_finish = value != 0;
         h->det_pending = false;

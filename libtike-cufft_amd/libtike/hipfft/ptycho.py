@@ -146,6 +146,10 @@ class PtychoHIP:
         nat.check(nat.set_option(self._h, b"deterministic", int(bool(on))))
         self._det = bool(on)
 
+    def release_scratch(self):
+        """Free the adjoint's intermediate (up to 4 GiB; ``adj`` allocates it again when needed): the fused CG loops never use it."""
+        nat.check(nat.set_option(self._h, b"release_scratch", 1))
+
     def set_fused(self, tiles=2):
         """ndet = 256: forward operator as one launch (``k_fwd_fused256``), ``tiles`` = 0 (off), 1 or 2."""
         nat.check(nat.set_option(self._h, b"fused", int(tiles)))
