@@ -749,8 +749,10 @@ class CGPtychoSolver(PtychoHIP):
             # with the position correction on, its two operands (column passes of fwd(psi, 1) and fwd(dpsi, 1)) ride
             # along with the object step's own column passes: one patch gather per position serves both probes
             share = bool(correct) and self.share_ones and self.ndet <= 512 and self.ptheta == 1
-            op = _ptr(ones) if share else None
-            nat.check(nat.cg_obj_begin2(h, sp, _ptr(psi), _ptr(scan), _ptr(probe), op, _ptr(data), S))
+            # with a process group the column pass of fwd(psi, 1) is better spent under the gradient all-reduce (below)
+            op_psi = _ptr(ones) if (share and not dist_on) else None
+            op_dpsi = _ptr(ones) if share else None
+            nat.check(nat.cg_obj_begin2(h, sp, _ptr(psi), _ptr(scan), _ptr(probe), op_psi, _ptr(data), S))
             if dist_on:
                 self._allreduce(st[nat.ST_A:nat.ST_A + 2])
             nat.check(nat.cg_obj_grad(h, sp, _ptr(scan), _ptr(probe), _ptr(data), _ptr(grad), S))
@@ -759,11 +761,11 @@ class CGPtychoSolver(PtychoHIP):
                 # correction (column pass of fwd(psi, 1): depends on psi and scan only) is computed under it
                 import torch.distributed as dist
                 work = dist.all_reduce(torch.view_as_real(grad), group=self.group, async_op=True)
-                if correct and not share:
+                if correct:
                     nat.check(nat.cg_reg_prepare(h, sp, _ptr(psi), _ptr(scan), _ptr(ones), S))
                     correct = 2
                 work.wait()
-            nat.check(nat.cg_obj_dir2(h, sp, first, _ptr(scan), _ptr(probe), op, _ptr(data), _ptr(grad),
+            nat.check(nat.cg_obj_dir2(h, sp, first, _ptr(scan), _ptr(probe), op_dpsi, _ptr(data), _ptr(grad),
                                       _ptr(grad0), _ptr(dpsi), S))
             if share:
                 correct = 3
