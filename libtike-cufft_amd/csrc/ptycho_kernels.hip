@@ -680,6 +680,7 @@ int do_adj_generic(ptycho_handle h, c32* f, const c32* g, const float* scan, c32
     const Geom& ge = h->ge;
     const long long total = (long long)ge.ptheta * ge.nscan;
     const size_t tile = (size_t)ge.ndet * ge.ndet;
+    if (h->deterministic) return fail(PTYCHO_ERR_ARG, "option deterministic needs a power-of-two detector size (16 .. 512)");
     // object adjoint: LDS overlap-add window over runs of sorted positions (k_adjwin_generic) when the window fits
     const size_t win_bytes = (size_t)(ge.nprb + 8) * (16 + kBucketPx) * sizeof(c32);
     bool windowed = flg == 0 && h->use_window && win_bytes + sizeof(RunMeta) + 256 <= 160 * 1024;

@@ -291,6 +291,12 @@ def test_error_behaviour(pt):
         slv.fwd(psi, scan, prb)
     with pytest.raises(NotImplementedError):
         pt.PtychoCuFFT(4, 16, 16, 1, 64, 64).run(None, None, None, None)
+    # options that a path does not cover fail loudly instead of being ignored
+    with pt.PtychoCuFFT(4, 30, 30, 1, 64, 64) as gen:               # Bluestein path: no fixed-point adjoints
+        gen.set_deterministic(True)
+        g = gen.fwd(psi, scan, torch.ones((1, 30, 30), dtype=torch.complex64, device="cuda"))
+        with pytest.raises(nat.PtychoHipError):
+            gen.adj(g, scan, torch.ones((1, 30, 30), dtype=torch.complex64, device="cuda"))
 
 
 # ---- detector sizes that are not a power of two (cuFFT takes any size, ptychofft.cu:13-20) ----------------
