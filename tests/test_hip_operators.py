@@ -197,6 +197,9 @@ def test_optional_paths_give_the_same_results(pt):
         slv.set_split(True)
         for a, b in zip(uns, ref):
             assert np.abs(a - b).max() <= 1e-5 * np.abs(b).max()
+        slv.release_scratch()              # the adjoint's intermediate is given back and allocated again on demand
+        again = host(slv.adj(yd, scan, prb))
+        assert np.abs(again - ref[1]).max() <= 1e-5 * np.abs(ref[1]).max()
 
 
 def test_fft2_matches_numpy(pt):
