@@ -288,8 +288,11 @@ __global__ __launch_bounds__(ColCfg<N>::NT) void k_cols_adjwin(const ColArgs a, 
 //   M_FWD     : v = (c*prb) * bilerp(window)  -> DFT over y -> strip of g
 //   M_ADJ_PRB : IDFT over y of the scratch strip; acc += near * conj(bilerp(window))
 // ---------------------------------------------------------------------------
-template <int N, int MODE, bool SPLIT = false, int NM = 1>
-__global__ __launch_bounds__(ColCfg<N>::NT) void k_cols_gatherwin(const ColArgs a, const int seglen) {
+// CW: columns per strip (0: ColCfg<N>::C).  The split forward pass of ndet = 256 runs 32-column strips (512 threads, two
+// workgroups = 16 waves per CU, 256-byte row pieces): 0.474 -> 0.455 ms against 16-column strips (round 3, A/B on one box;
+// the object adjoint loses with them: one workgroup of eight waves per CU).
+template <int N, int MODE, bool SPLIT = false, int NM = 1, int CW = 0>
+__global__ __launch_bounds__(Plan<N>::T * (CW ? CW : ColCfg<N>::C)) void k_cols_gatherwin(const ColArgs a, const int seglen) {
     // SPLIT (N = 256): only one radix-16 step of the DFT over y runs here (thread local, no
     // exchange buffer -> 44 KiB of LDS, three workgroups per CU); k_rows_split does the other.
     // NM > 1 (forward only): NM probe modes per launch.  The bilinear patch values of a position are
@@ -300,9 +303,9 @@ __global__ __launch_bounds__(ColCfg<N>::NT) void k_cols_gatherwin(const ColArgs 
     using P = Plan<N>;
     constexpr int DIR = (MODE == M_FWD) ? -1 : +1;
     using F = Fft<P, DIR>;
-    constexpr int E = P::E, T = P::T, C = ColCfg<N>::C, NT = ColCfg<N>::NT;
+    constexpr int E = P::E, T = P::T, C = CW ? CW : ColCfg<N>::C, NT = T * C;
     constexpr int LAST = P::NSTEP - 1;
-    constexpr int WC = WinCfg<N>::WC, H = WinCfg<N>::H;
+    constexpr int WC = C + kBucketPx, H = WinCfg<N>::H;
     constexpr int R0 = P::radix(0), RL = P::radix(LAST), NsL = P::ns(LAST);
     __shared__ c32 lds[SPLIT ? 1 : N * C];
     // window rows are addressed modulo H; row H mirrors row 0, so the tap of the row below never wraps and both rows

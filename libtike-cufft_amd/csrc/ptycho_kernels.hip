@@ -208,7 +208,7 @@ int launch_adjwin(ptycho_handle h, ColArgs a, hipStream_t st, int wg_target = 0)
     const int np = a.k_end - a.k_begin;
     if (np <= 0 || a.nstrips <= 0) return PTYCHO_OK;
     // contiguous runs of the sorted order; about 4 workgroups per CU in total
-    if (wg_target <= 0) wg_target = h->n_cu * 4;
+    if (wg_target <= 0) wg_target = h->n_cu * 4;   // (two rounds; one round of runs of 128: within 1 %, six or eight rounds: +4 %)
     int nseg = (wg_target + a.nstrips - 1) / a.nstrips;
     if (nseg < 1) nseg = 1;
     int seglen = (np + nseg - 1) / nseg;
@@ -228,12 +228,14 @@ int launch_adjwin(ptycho_handle h, ColArgs a, hipStream_t st, int wg_target = 0)
     return PTYCHO_OK;
 }
 
-template <int N, int MODE, bool SPLIT = false>
+template <int N, int MODE, bool SPLIT = false, int CW = 0>
 int launch_gatherwin(ptycho_handle h, ColArgs a, hipStream_t st, int wg_target = 0) {
-    using CC = ColCfg<N>;
+    constexpr int NTHREADS = Plan<N>::T * (CW ? CW : ColCfg<N>::C);
     const int np = a.k_end - a.k_begin;
     if (np <= 0 || a.nstrips <= 0) return PTYCHO_OK;
-    if (wg_target <= 0) wg_target = h->n_cu * (SPLIT ? 6 : 4);   // split kernels fit three per CU
+    // whole rounds of resident workgroups (two per CU un-split, three split): a ragged last round costs 5-20 % (round 3: 1.5
+    // rounds of the un-split forward pass made the CG iteration 8.43 -> 8.87 ms; one long round 8.49)
+    if (wg_target <= 0) wg_target = h->n_cu * (SPLIT ? 6 : 4);
     int nseg = (wg_target + a.nstrips - 1) / a.nstrips;
     if (nseg < 1) nseg = 1;
     int seglen = (np + nseg - 1) / nseg;
@@ -257,7 +259,7 @@ int launch_gatherwin(ptycho_handle h, ColArgs a, hipStream_t st, int wg_target =
 #endif
     {
         ProfSpan ps(h, MODE == M_FWD ? K_COLS_FWD : K_COLS_ADJ_PRB, st);
-        hipLaunchKernelGGL((k_cols_gatherwin<N, MODE, SPLIT>), dim3((unsigned)(a.nstrips * nseg)), dim3(CC::NT), 0, st, a, seglen);
+        hipLaunchKernelGGL((k_cols_gatherwin<N, MODE, SPLIT, 1, CW>), dim3((unsigned)(a.nstrips * nseg)), dim3(NTHREADS), 0, st, a, seglen);
     }
     HIP_TRY(hipGetLastError());
     return PTYCHO_OK;
@@ -362,8 +364,15 @@ int do_fwd(ptycho_handle h, c32* g, const c32* f, const float* scan, const c32* 
     ra.nrows = total * N; ra.xa = strip0 * C; ra.xb = (strip0 + nstrips) * C; ra.wa = 0; ra.wb = N;
     if constexpr (N == 256) {
         if (window && h->use_split) {
+            // 32-column strips: the strip range and the row pass's column limits follow the wider strips
+            constexpr int CF = 32;
             ca.order = h->order;
-            rc = launch_gatherwin<N, M_FWD, true>(h, ca, st);
+            ca.strip0 = ge.pad / CF;
+            ca.nstrips = (ge.pad + ge.nprb - 1) / CF - ca.strip0 + 1;
+            ra.xa = ca.strip0 * CF; ra.xb = (ca.strip0 + ca.nstrips) * CF;
+            // exactly one resident round of workgroups (two per CU), runs of 64 positions at 4096: 0.42 -> 0.395 ms against
+            // two rounds of shorter runs; 1.5 or 3 rounds (a ragged tail) cost 10-20 % (profiles/r03/knob_sweep.txt)
+            rc = launch_gatherwin<N, M_FWD, true, CF>(h, ca, st, h->n_cu * 2);
             if (rc) return rc;
             return launch_rows_split<N, -1>(h, ra, st);
         }
