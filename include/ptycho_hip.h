@@ -269,8 +269,8 @@ int ptycho_cg_cross_dev(ptycho_handle h, int slot1, int slot2, const double* gam
  * "split" (ndet = 256: 1 = one radix-16 step of the DFT over y runs in the row pass [default]);
  * "deterministic" (1 = the adjoints add their per-workgroup sums into a 64-bit fixed-point image with integer
  * atomics and fold it into the output once: bitwise reproducible for a given chunk / run partition, one extra read of
- * g for the scale (none after ptycho_cg_project, which leaves max |slot| on the device); needs the windowed kernels,
- * ndet <= 512; default 0: float atomics, as kernels.cu:73-80,92-93);
+ * g for the scale (none after ptycho_cg_project, which leaves max |slot| on the device); needs the windowed kernels
+ * (powers of two up to 512, or any other size with nprb <= ~1000); default 0: float atomics, as kernels.cu:73-80,92-93);
  * "compact_modes" (M = number of probe modes: compact slot layout + chunk-major position order, see above; 0 = slot pairs);
  * "defer_finish", "ls_fused_decide" (native CG stages on one GPU, see above; default 0);
  * "release_scratch" (any value: frees the adjoint's intermediate, which the fused CG stages never use; ptycho_adj re-allocates it);

@@ -149,9 +149,22 @@ __global__ void k_adj_obj_generic(c32* __restrict__ f, const c32* __restrict__ p
 
 // probe adjoint (kernels.cu:82-94): one thread per probe pixel and group of positions, partial sum in registers
 __global__ void k_adj_prb_generic(const c32* __restrict__ f, c32* __restrict__ prb, const float* __restrict__ scan,
-                                  const c32* __restrict__ near, const Geom ge, const int p0, const int p1, const int pgroup) {
+                                  const c32* __restrict__ near, const Geom ge, const int p0, const int p1, const int pgroup,
+                                  long long* __restrict__ det_acc, const DetScale det) {
     const int pix = blockIdx.x * blockDim.x + threadIdx.x;
     if (pix >= ge.nprb * ge.nprb) return;
+    const float det_sc = det_acc ? det_scale_of(det) : 0.0f;
+    auto add = [&](int t, int iy, int ix, c32 v) {   // one group's share of prb[t][iy][ix]
+        const size_t e = ((size_t)t * ge.nprb + iy) * ge.nprb + ix;
+        if (det_acc) {
+            atomicAdd(reinterpret_cast<unsigned long long*>(det_acc + 2 * e), (unsigned long long)__float2ll_rn(v.x * det_sc));
+            atomicAdd(reinterpret_cast<unsigned long long*>(det_acc + 2 * e + 1), (unsigned long long)__float2ll_rn(v.y * det_sc));
+        } else {
+            float* o = reinterpret_cast<float*>(prb + e);
+            atomicAdd(o, v.x);
+            atomicAdd(o + 1, v.y);
+        }
+    };
     const int ix = pix % ge.nprb, iy = pix / ge.nprb;
     const int N = ge.ndet;
     const int pa = p0 + blockIdx.y * pgroup;
@@ -161,9 +174,7 @@ __global__ void k_adj_prb_generic(const c32* __restrict__ f, c32* __restrict__ p
     for (int p = pa; p < pb; ++p) {
         const int t = p / ge.nscan;
         if (t != cur_t && cur_t >= 0) {
-            float* o = reinterpret_cast<float*>(prb + ((size_t)cur_t * ge.nprb + iy) * ge.nprb + ix);
-            atomicAdd(o, acc.x * (1.0f / (float)N));
-            atomicAdd(o + 1, acc.y * (1.0f / (float)N));
+            add(cur_t, iy, ix, acc * (1.0f / (float)N));
             acc = c32{0.0f, 0.0f};
         }
         cur_t = t;
@@ -172,11 +183,7 @@ __global__ void k_adj_prb_generic(const c32* __restrict__ f, c32* __restrict__ p
         const c32 patch = bilerp(f + (size_t)t * ge.nz * ge.n, q.sy + iy, q.sx + ix, q, ge);
         acc += cmulc(near[((size_t)(p - p0) * N + iy + ge.pad) * N + ix + ge.pad], patch);
     }
-    if (cur_t >= 0) {
-        float* o = reinterpret_cast<float*>(prb + ((size_t)cur_t * ge.nprb + iy) * ge.nprb + ix);
-        atomicAdd(o, acc.x * (1.0f / (float)N));
-        atomicAdd(o + 1, acc.y * (1.0f / (float)N));
-    }
+    if (cur_t >= 0) add(cur_t, iy, ix, acc * (1.0f / (float)N));
 }
 
 
@@ -199,6 +206,7 @@ __global__ __launch_bounds__(256) void k_adjwin_generic(const ColArgs a, const i
     const float cinv = 1.0f / (float)N;
     const c32 zero = c32{0.0f, 0.0f};
     for (int o = tid; o < H * WC; o += NT) gwin[o] = zero;
+    const float det_sc = a.det_acc ? det_scale_of(a.det) : 0.0f;   // option deterministic: float -> 64-bit fixed point
     int t_w = -1, X0 = 0, Ybase = 0, Ytop = 0;     // live object rows [Ybase, Ytop), columns [X0, X0 + WC)
 
     auto flush = [&](int ya, int yb) {             // add rows [ya, yb) to the object and clear them
@@ -211,9 +219,15 @@ __global__ __launch_bounds__(256) void k_adjwin_generic(const ColArgs a, const i
             gwin[slot] = zero;
             const int X = X0 + col;
             if ((v.x != 0.0f || v.y != 0.0f) && Y < ge.nz && X >= 0 && X < ge.n) {
-                float* op = reinterpret_cast<float*>(a.dst + ((size_t)t_w * ge.nz + Y) * ge.n + X);
-                atomicAdd(op, v.x);
-                atomicAdd(op + 1, v.y);
+                const size_t e = ((size_t)t_w * ge.nz + Y) * ge.n + X;
+                if (a.det_acc) {   // integer atomics: the sum does not depend on the arrival order
+                    atomicAdd(reinterpret_cast<unsigned long long*>(a.det_acc + 2 * e), (unsigned long long)__float2ll_rn(v.x * det_sc));
+                    atomicAdd(reinterpret_cast<unsigned long long*>(a.det_acc + 2 * e + 1), (unsigned long long)__float2ll_rn(v.y * det_sc));
+                } else {
+                    float* op = reinterpret_cast<float*>(a.dst + e);
+                    atomicAdd(op, v.x);
+                    atomicAdd(op + 1, v.y);
+                }
             }
         }
     };

@@ -689,7 +689,6 @@ int do_adj_generic(ptycho_handle h, c32* f, const c32* g, const float* scan, c32
     const Geom& ge = h->ge;
     const long long total = (long long)ge.ptheta * ge.nscan;
     const size_t tile = (size_t)ge.ndet * ge.ndet;
-    if (h->deterministic) return fail(PTYCHO_ERR_ARG, "option deterministic needs a power-of-two detector size (16 .. 512)");
     // object adjoint: LDS overlap-add window over runs of sorted positions (k_adjwin_generic) when the window fits
     const size_t win_bytes = (size_t)(ge.nprb + 8) * (16 + kBucketPx) * sizeof(c32);
     bool windowed = flg == 0 && h->use_window && win_bytes + sizeof(RunMeta) + 256 <= 160 * 1024;
@@ -700,6 +699,13 @@ int do_adj_generic(ptycho_handle h, c32* f, const c32* g, const float* scan, c32
     }
     if (windowed) {
         int rc = sort_positions(h, scan, st);
+        if (rc) return rc;
+    }
+    ColArgs det{};
+    if (h->deterministic) {   // per-workgroup sums into the 64-bit fixed-point image (integer atomics), folded in at the end
+        if (flg == 0 && !windowed) return fail(PTYCHO_ERR_ARG, "option deterministic needs the windowed object adjoint (option window, nprb <= ~1000)");
+        int rc = det_begin(h, det, g, total * (long long)tile, flg == 0 ? prb : f,
+                           flg == 0 ? (long long)ge.ptheta * ge.nprb * ge.nprb : (long long)ge.ptheta * ge.nz * ge.n, flg, st);
         if (rc) return rc;
     }
     for (long long k0 = 0; k0 < total; k0 += h->chunk) {
@@ -713,6 +719,7 @@ int do_adj_generic(ptycho_handle h, c32* f, const c32* g, const float* scan, c32
             ColArgs ca{};
             ca.src = h->scratch; ca.dst = f; ca.aux = prb; ca.scan = scan; ca.ge = ge; ca.order = h->order;
             ca.k_begin = (int)k0; ca.k_end = (int)k1; ca.strip0 = 0; ca.nstrips = (ge.nprb + 15) / 16;
+            ca.det_acc = det.det_acc; ca.det = det.det;
             const int np = (int)(k1 - k0);
             int nseg = (h->n_cu * 4 + ca.nstrips - 1) / ca.nstrips;
             if (nseg < 1) nseg = 1;
@@ -734,10 +741,11 @@ int do_adj_generic(ptycho_handle h, c32* f, const c32* g, const float* scan, c32
             const int pgroup = (int)((k1 - k0 + groups - 1) / groups);
             ProfSpan ps(h, K_COLS_ADJ_PRB, st);
             hipLaunchKernelGGL(k_adj_prb_generic, dim3((unsigned)((npp + 255) / 256), (unsigned)groups), dim3(256), 0, st,
-                               (const c32*)f, prb, scan, (const c32*)h->scratch, ge, (int)k0, (int)k1, pgroup);
+                               (const c32*)f, prb, scan, (const c32*)h->scratch, ge, (int)k0, (int)k1, pgroup, det.det_acc, det.det);
         }
         HIP_TRY(hipGetLastError());
     }
+    if (h->deterministic) return det_end(h, flg == 0 ? f : prb, flg, st);
     return PTYCHO_OK;
 }
 

@@ -202,6 +202,24 @@ def test_optional_paths_give_the_same_results(pt):
         assert np.abs(again - ref[1]).max() <= 1e-5 * np.abs(ref[1]).max()
 
 
+def test_deterministic_adjoints_at_a_size_that_is_not_a_power_of_two(pt):
+    """Option deterministic on the Bluestein path (ndet 112): both adjoints equal the float-atomic ones to rounding and
+    are bitwise equal between two calls."""
+    import torch
+    p = syn.make_problem(12, 12, 6, 112, 112, seed=8)
+    rng = np.random.default_rng(2)
+    y = (rng.standard_normal((1, 144, 112, 112)) + 1j * rng.standard_normal((1, 144, 112, 112))).astype(np.complex64)
+    with pt.PtychoCuFFT(144, 112, 112, 1, p["nz"], p["n"]) as slv:
+        psi, scan, prb, yd = dev(p["psi"]), dev(p["scan"]), dev(p["probe"]), dev(y)
+        ref = [host(slv.adj(yd, scan, prb)), host(slv.adj_probe(yd, scan, psi))]
+        slv.set_deterministic(True)
+        a1 = [host(slv.adj(yd, scan, prb)), host(slv.adj_probe(yd, scan, psi))]
+        a2 = [host(slv.adj(yd, scan, prb)), host(slv.adj_probe(yd, scan, psi))]
+    for r, x1, x2 in zip(ref, a1, a2):
+        assert np.array_equal(x1, x2)
+        assert np.abs(x1 - r).max() <= 2e-6 * np.abs(r).max()
+
+
 def test_fft2_matches_numpy(pt):
     rng = np.random.default_rng(0)
     for ndet in (16, 32, 64, 128, 256, 512, 1024, 2048):
@@ -295,8 +313,9 @@ def test_error_behaviour(pt):
     with pytest.raises(NotImplementedError):
         pt.PtychoCuFFT(4, 16, 16, 1, 64, 64).run(None, None, None, None)
     # options that a path does not cover fail loudly instead of being ignored
-    with pt.PtychoCuFFT(4, 30, 30, 1, 64, 64) as gen:               # Bluestein path: no fixed-point adjoints
+    with pt.PtychoCuFFT(4, 30, 30, 1, 64, 64) as gen:               # Bluestein path without its window: no fixed-point object adjoint
         gen.set_deterministic(True)
+        gen.set_window(False)
         g = gen.fwd(psi, scan, torch.ones((1, 30, 30), dtype=torch.complex64, device="cuda"))
         with pytest.raises(nat.PtychoHipError):
             gen.adj(g, scan, torch.ones((1, 30, 30), dtype=torch.complex64, device="cuda"))
