@@ -207,10 +207,24 @@ def generic_figures(pt, syn, dev):
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / 10 * 1e3
     slv.free()
+    # the CG loop at such a size: the statement-by-statement loop (reference expressions in torch) around these operators
+    cg = pt.CGPtychoSolver(R * R, ndet, ndet, 1, nz, n)
+    cg.verbose = False
+    prs = torch.as_tensor((syn.gaussian_probe(ndet) * np.exp(2j * np.pi * rng.random((ndet, ndet)))).astype(np.complex64), device=dev)
+    data = (torch.abs(cg.fwd(psi, scan, prs)) ** 2).contiguous()
+    cg.run(data, torch.ones_like(psi), scan.clone(), prs[:, None].clone(), piter=2)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    cg.run(data, torch.ones_like(psi), scan.clone(), prs[:, None].clone(), piter=6)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / 6
+    cg.free()
     pair_bytes = 2.0 * (8.0 * R * R * ndet * ndet + 8.0 * nz * n + 8.0 * ndet * ndet + 8.0 * R * R)
     return {"generic112_workload": "4096 positions x (112x112), nprb 112: detector size that is not a power of two (Bluestein path)",
             "generic112_pair_ms": ms, "generic112_patterns_per_s": R * R / (ms * 1e-3),
-            "generic112_roofline_frac": pair_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+            "generic112_roofline_frac": pair_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "generic112_cg_it_s": 1.0 / dt,
+            "generic112_cg_note": "statement-by-statement CG loop (torch elementwise around the HIP operators), phase-screened probe, position correction on"}
 
 
 def cpu_baseline(args, prob):
@@ -560,13 +574,14 @@ def main():
     elif rank == 0:
         out["cpu_baseline"] = None
     slv.free()
-    if ngpu == 1 and not dist and not args.no_cfg3 and not args.no_cg:
-        try:
-            del psi, scan, prb
-            torch.cuda.empty_cache()
-            out.update(cfg3_figures(pt, syn, dev, args.cfg3_iters))
-        except Exception as e:          # never let a secondary figure break the primary line
-            print("configs[2] figures failed: %r" % (e,), file=sys.stderr)
+    if ngpu == 1 and not dist and not args.no_cg:
+        del psi, scan, prb
+        torch.cuda.empty_cache()
+        if not args.no_cfg3:
+            try:
+                out.update(cfg3_figures(pt, syn, dev, args.cfg3_iters))
+            except Exception as e:          # never let a secondary figure break the primary line
+                print("configs[2] figures failed: %r" % (e,), file=sys.stderr)
         try:
             out.update(generic_figures(pt, syn, dev))
         except Exception as e:
