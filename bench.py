@@ -227,6 +227,47 @@ def generic_figures(pt, syn, dev):
             "generic112_cg_note": "statement-by-statement CG loop (torch elementwise around the HIP operators), phase-screened probe, position correction on"}
 
 
+def small_tile_figures(pt, syn, dev):
+    """fwd / adj at detector sizes whose tile fits one compute unit's LDS (the reference's own tests run ndet = 128,
+    tests/test_adjoint.py:18; configs[0] is 64): the forward operator and the probe adjoint are ONE launch each, the
+    column<->row intermediate never reaches HBM (k_tile.hpp).  4096 positions, raster step 8 + jitter."""
+    out = {}
+    for ndet in (128, 64):
+        R, step = 64, 8
+        nz, n = syn.object_size_for(R, R, step, ndet)
+        rng = np.random.default_rng(778)
+        psi = torch.as_tensor(syn.random_object(nz, n, rng), device=dev)
+        scan = torch.as_tensor(syn.raster_scan(R, R, step, rng), device=dev)
+        prb = torch.as_tensor(syn.gaussian_probe(ndet), device=dev)
+        slv = pt.PtychoCuFFT(R * R, ndet, ndet, 1, nz, n)
+        g = torch.empty((1, R * R, ndet, ndet), dtype=torch.complex64, device=dev)
+        o = torch.empty_like(psi)
+
+        def timed(fn, reps=20):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            for _ in range(3):
+                fn()
+            e0.record()
+            for _ in range(reps):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) / reps
+        tf = timed(lambda: slv.fwd(psi, scan, prb, out=g))
+        ta = timed(lambda: slv.adj(g, scan, prb, out=o))
+        slv.set_tile(False)
+        tf2 = timed(lambda: slv.fwd(psi, scan, prb, out=g))
+        ta2 = timed(lambda: slv.adj(g, scan, prb, out=o))
+        slv.free()
+        op_bytes = 8.0 * R * R * ndet * ndet + 8.0 * nz * n + 8.0 * ndet * ndet + 8.0 * R * R
+        k = "ndet%d_" % ndet
+        out.update({k + "fwd_ms": tf, k + "adj_ms": ta, k + "fwd_roofline_frac": op_bytes / (tf * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    k + "pair_roofline_frac": 2 * op_bytes / ((tf + ta) * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    k + "two_pass_fwd_ms": tf2, k + "two_pass_adj_ms": ta2})
+    out["ndet_small_workload"] = "4096 positions x (128x128) and x (64x64), nprb = ndet: one-launch forward (tile in LDS); *_two_pass_* = option tile 0"
+    return out
+
+
 def cpu_baseline(args, prob):
     """The reference ships no CPU path (``array_module = cp`` only), so the CPU figures are the oracle's
     (SURVEY.md 8d), timed on this host: (1) fwd+adj patterns/s with scipy.fft on all cores -- ``value`` --,
@@ -584,6 +625,7 @@ def main():
                 print("configs[2] figures failed: %r" % (e,), file=sys.stderr)
         try:
             out.update(generic_figures(pt, syn, dev))
+            out.update(small_tile_figures(pt, syn, dev))
         except Exception as e:
             print("generic-size figures failed: %r" % (e,), file=sys.stderr)
         if not args.no_shard:

@@ -267,6 +267,8 @@ int ptycho_cg_cross_dev(ptycho_handle h, int slot1, int slot2, const double* gam
  * same pointer with unchanged contents as in the previous call, so the position sort is
  * reused; set 0 after modifying scan; default 0);
  * "split" (ndet = 256: 1 = one radix-16 step of the DFT over y runs in the row pass [default]);
+ * "tile" (ndet <= 128: 1 = forward operator and probe adjoint as ONE launch each, the tile stays in the CU's LDS and the
+ * column<->row intermediate never reaches HBM [default]; 0 = the two-pass kernels of the larger sizes);
  * "deterministic" (1 = the adjoints add their per-workgroup sums into a 64-bit fixed-point image with integer
  * atomics and fold it into the output once: bitwise reproducible for a given chunk / run partition, one extra read of
  * g for the scale (none after ptycho_cg_project, which leaves max |slot| on the device); needs the windowed kernels
@@ -289,7 +291,7 @@ int ptycho_set_option(ptycho_handle h, const char* name, long long value);
  * (index 0 k_cols<FWD>, 1 k_rows<fwd>, 2 k_rows<inv>, 3 k_cols<ADJ_OBJ>,
  * 4 k_cols<ADJ_PRB>, 5 k_cols<PLAIN>, 6 position sort, 7 / 8 / 9 fused CG row passes (statistics / projection /
  * line search), 10 unused, 11 single-launch forward (experiments build), 12 unused, 13 cross row pass,
- * 14 arg-max column pass, 15 zoomed DFT + arg-max; n >= 16)
+ * 14 arg-max column pass, 15 zoomed DFT + arg-max, 16 / 17 one-launch forward / probe adjoint of ndet <= 128; n >= 18)
  * and clears the record.
  * No counterpart in the reference (it has no timing code). */
 int ptycho_profile(ptycho_handle h, int enable);

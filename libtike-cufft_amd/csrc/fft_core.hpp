@@ -171,6 +171,25 @@ struct Fft {
         }
     }
 
+    // step ST with its twiddles read from `table` (an LDS copy of the plan's table) as they are used: no twiddle
+    // registers at all (the kernels of k_tile.hpp run 1024 threads on 128 registers each)
+    template <int ST>
+    PTY_FN void compute_tab(c32* v, int j0, const c32* table) const {
+        constexpr int R = P::radix(ST), Ns = P::ns(ST);
+#pragma unroll
+        for (int b = 0; b < E / R; ++b) {
+            if (ST > 0) {
+                const int j = j0 + b * T;
+#pragma unroll
+                for (int t = 1; t < R; ++t) {
+                    const c32 w = table[((j % Ns) * t * (N / (Ns * R))) & (N - 1)];
+                    v[b * R + t] = cmul(v[b * R + t], DIR < 0 ? w : cconj(w));
+                }
+            }
+            fft_reg<R, DIR>(v + b * R);
+        }
+    }
+
     // same step in the opposite direction (conjugate twiddles): lets one kernel run a
     // forward and an inverse transform with a single set of twiddle registers
     template <int ST>

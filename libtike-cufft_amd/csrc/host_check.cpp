@@ -27,6 +27,7 @@ static double check_plan() {
     for (int j0 = 0; j0 < T; ++j0) th[j0].init(j0, table.data());
     c32* cur = nullptr;
     c32* nxt = bufA.data();
+    bool tab_bad = false;
     auto phase = [&](auto stc) {
         constexpr int ST = decltype(stc)::value;
         for (int j0 = 0; j0 < T; ++j0) {
@@ -34,7 +35,12 @@ static double check_plan() {
                 th[j0].template load<ST>(v[j0].data(), j0, [&](int i) { return x[i]; });
             else
                 th[j0].template load<ST>(v[j0].data(), j0, [&](int i) { return cur[RowLds<N>::at(0, i)]; });
+            // compute_tab (twiddles read from the table as they are used, k_tile.hpp) must equal compute bit for bit
+            std::vector<c32> vt(v[j0]);
             th[j0].template compute<ST>(v[j0].data());
+            th[j0].template compute_tab<ST>(vt.data(), j0, table.data());
+            for (int m = 0; m < E; ++m)
+                if (vt[m].x != v[j0][m].x || vt[m].y != v[j0][m].y) { std::printf("compute_tab mismatch N=%d step %d\n", N, ST); tab_bad = true; }
         }
         for (int j0 = 0; j0 < T; ++j0) {
             if (ST == P::NSTEP - 1)
@@ -60,6 +66,7 @@ static double check_plan() {
         for (int m = 0; m < E; ++m)
             if (back[m].x != chk[m].x || back[m].y != chk[m].y) { std::printf("from_natural mismatch N=%d\n", N); return 1.0; }
     }
+    if (tab_bad) return 1.0;
     double err = 0, nrm = 0;
     for (int k = 0; k < N; ++k) {
         std::complex<double> acc = 0;

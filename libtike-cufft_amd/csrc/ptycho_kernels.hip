@@ -46,6 +46,7 @@ namespace {
 #include "k_cg_small.hpp"
 #include "k_generic.hpp"
 #include "k_zoom.hpp"
+#include "k_tile.hpp"
 
 // ---------------------------------------------------------------------------
 // host side
@@ -64,7 +65,7 @@ constexpr int exp_env(const char*, int dflt) { return dflt; }
 #endif
 
 // kernel ids for the in-library profiler (ptycho_profile_read)
-enum { K_COLS_FWD = 0, K_ROWS_FWD = 1, K_ROWS_INV = 2, K_COLS_ADJ_OBJ = 3, K_COLS_ADJ_PRB = 4, K_COLS_PLAIN = 5, K_SORT = 6, K_ROWS_STATS = 7, K_ROWS_PROJECT = 8, K_ROWS_LINESEARCH = 9, K_CG_SCALARS = 10, K_FWD_FUSED = 11, K_CG_UPDATE = 12, K_ROWS_CROSS = 13, K_COLS_ARGMAX = 14, K_ZOOM = 15, K_COUNT = 16 };
+enum { K_COLS_FWD = 0, K_ROWS_FWD = 1, K_ROWS_INV = 2, K_COLS_ADJ_OBJ = 3, K_COLS_ADJ_PRB = 4, K_COLS_PLAIN = 5, K_SORT = 6, K_ROWS_STATS = 7, K_ROWS_PROJECT = 8, K_ROWS_LINESEARCH = 9, K_CG_SCALARS = 10, K_FWD_FUSED = 11, K_CG_UPDATE = 12, K_ROWS_CROSS = 13, K_COLS_ARGMAX = 14, K_ZOOM = 15, K_TILE_FWD = 16, K_TILE_ADJ_PRB = 17, K_COUNT = 18 };
 
 int fail(int code, const std::string& msg) {
     g_err = msg;
@@ -101,6 +102,7 @@ struct ptycho_handle_s {
     double* reg_shifts = nullptr;         // sub-pixel shifts [positions][2]
     int use_window = 1;       // 0: direct-atomics object adjoint (k_cols<ADJ_OBJ>)
     int use_split = 1;        // ndet = 256: one radix-16 step of the DFT over y runs in the row pass
+    int use_tile = 1;         // ndet <= 128: one-launch forward / probe adjoint, the tile stays in LDS (k_tile.hpp)
     int deterministic = 0;    // 1: adjoints accumulate in 64-bit fixed point (integer atomics): bitwise reproducible results
     long long* det_acc = nullptr;   // fixed-point image, 2 words per object (or probe) element, kept zero between calls
     double* det_words = nullptr;    // device: max |g|, max |probe or object| as float bits (k_cg_absmax)
@@ -335,6 +337,47 @@ int do_fwd_fused(ptycho_handle h, c32* g, const c32* f, const float* scan, const
 }
 #endif
 
+// ---- one-launch operators for ndet <= 128 (k_tile.hpp): persistent workgroups, as many as fit a CU's LDS ----
+template <int N>
+unsigned tile_grid(ptycho_handle h, long long npos, int max_per_cu = 0) {
+    using CF = TileCfg<N>;
+    int per_cu = (int)((160 * 1024) / CF::lds_bytes);
+    if (per_cu * CF::NT > 2048) per_cu = 2048 / CF::NT;
+    if (max_per_cu > 0 && per_cu > max_per_cu) per_cu = max_per_cu;
+    if (per_cu < 1) per_cu = 1;
+    long long wg = (npos + CF::TPW - 1) / CF::TPW;
+    const long long cap = (long long)h->n_cu * per_cu;
+    return (unsigned)(wg < cap ? (wg < 1 ? 1 : wg) : cap);
+}
+template <int N>
+int launch_fwd_tile(ptycho_handle h, c32* g, const c32* f, const float* scan, const c32* prb, hipStream_t st) {
+    const Geom& ge = h->ge;
+    TileArgs ta{};
+    ta.obj = f; ta.prb = prb; ta.g = g; ta.scan = scan; ta.table = h->table; ta.ge = ge;
+    ta.npos = (int)((long long)ge.ptheta * ge.nscan);
+    {
+        ProfSpan ps(h, K_TILE_FWD, st);
+        hipLaunchKernelGGL((k_fwd_tile<N>), dim3(tile_grid<N>(h, ta.npos)), dim3(TileCfg<N>::NT), 0, st, ta);
+    }
+    HIP_TRY(hipGetLastError());
+    return PTYCHO_OK;
+}
+template <int N>
+int launch_adjprb_tile(ptycho_handle h, c32* prb_out, const c32* g, const float* scan, const c32* f, hipStream_t st) {
+    const Geom& ge = h->ge;
+    TileArgs ta{};
+    ta.obj = f; ta.g = const_cast<c32*>(g); ta.out = prb_out; ta.scan = scan; ta.table = h->table; ta.ge = ge;
+    ta.npos = (int)((long long)ge.ptheta * ge.nscan);
+    {
+        ProfSpan ps(h, K_TILE_ADJ_PRB, st);
+                // every workgroup ends with one atomic pair per probe pixel, all on the same ndet^2 addresses: few, long-running
+        // workgroups (four per CU: 1.90 ms at 16384 x 16^2, 0.27 at 32^2, 0.108 at 4096 x 64^2; one / two: 0.040, 0.093, 0.096)
+        hipLaunchKernelGGL((k_adjprb_tile<N>), dim3(tile_grid<N>(h, ta.npos, N <= 16 ? 1 : 2)), dim3(TileCfg<N>::NT), 0, st, ta);
+    }
+    HIP_TRY(hipGetLastError());
+    return PTYCHO_OK;
+}
+
 template <int N>
 int do_fwd(ptycho_handle h, c32* g, const c32* f, const float* scan, const c32* prb, hipStream_t st) {
     constexpr int C = ColCfg<N>::C;
@@ -344,6 +387,10 @@ int do_fwd(ptycho_handle h, c32* g, const c32* f, const float* scan, const c32* 
     strip_range<N>(ge, strip0, nstrips);
     const bool window = h->use_window && WinCfg<N>::fits;
     int rc = PTYCHO_OK;
+    if constexpr (N <= 128) {
+        // the tile fits one CU's LDS: one launch, no intermediate in HBM, no position sort (16-byte rows of g)
+        if (h->use_tile && ((size_t)g % 16) == 0 && (long long)ge.nz * ge.n < (1ll << 28)) return launch_fwd_tile<N>(h, g, f, scan, prb, st);
+    }
 #ifdef PTYCHO_EXPERIMENTS
     if constexpr (N == 256) {
         // single launch, no intermediate in HBM; needs 16-byte aligned object rows
@@ -442,6 +489,12 @@ int do_adj(ptycho_handle h, c32* f, const c32* g, const float* scan, c32* prb, i
     int strip0, nstrips;
     strip_range<N>(ge, strip0, nstrips);
     const bool window = flg == 0 && h->use_window && WinCfg<N>::fits;
+    if constexpr (N <= 128) {
+        // probe adjoint with the tile in LDS: one launch, g read once, no scratch, no position sort
+        // (at ndet = 128 the 16 accumulators per thread do not fit 128 registers next to the transforms: 0.48 against 0.45 ms)
+        if (N <= 64 && flg == 1 && h->use_tile && !h->deterministic && ((size_t)g % 16) == 0 && (long long)ge.nz * ge.n < (1ll << 28))
+            return launch_adjprb_tile<N>(h, prb, g, scan, f, st);
+    }
     // positions are visited in sorted order (angle, column bucket, row): neighbours in the
     // object are neighbours in time, which is what the LDS overlap-add window needs
     int rc = sort_positions(h, scan, st);
@@ -457,12 +510,22 @@ int do_adj(ptycho_handle h, c32* f, const c32* g, const float* scan, c32* prb, i
         RowArgs ra{};
         ra.src = g; ra.dst = h->scratch; ra.table = h->table; ra.tile_index = h->order + k0;
         ra.nrows = (k1 - k0) * N; ra.xa = 0; ra.xb = N; ra.wa = strip0 * C; ra.wb = (strip0 + nstrips) * C;
-        bool split = false;
+        bool split = false, tiled = false;
         if constexpr (N == 256) split = h->use_split && h->use_window;
         if constexpr (N == 256) {
             if (split) rc = launch_rows_split<N, +1>(h, ra, st);
         }
-        if (!split) rc = launch_rows<N, +1>(h, ra, st);
+        if constexpr (N <= 64) {
+            // whole tiles through LDS, 16 bytes per lane (k_tile.hpp): 0.34 -> 0.06 ms at 16384 x 32^2
+            tiled = h->use_tile && ((size_t)g % 16) == 0;
+            if (tiled) {
+                ProfSpan ps(h, K_ROWS_INV, st);
+                hipLaunchKernelGGL((k_rows_tile<N, +1>), dim3(tile_grid<N>(h, k1 - k0)), dim3(TileCfg<N>::NT), 0, st, g, h->scratch,
+                                   (const int*)(h->order + k0), (int)(k1 - k0), (const c32*)h->table);
+                HIP_TRY(hipGetLastError());
+            }
+        }
+        if (!split && !tiled) rc = launch_rows<N, +1>(h, ra, st);
         if (rc) return rc;
         ColArgs ca{};
         ca.src = h->scratch; ca.scan = scan; ca.table = h->table; ca.ge = ge;
@@ -986,6 +1049,10 @@ int ptycho_set_option(ptycho_handle h, const char* name, long long value) {
         h->use_split = value != 0;
         return PTYCHO_OK;
     }
+    if (std::strcmp(name, "tile") == 0) {
+        h->use_tile = value != 0;
+        return PTYCHO_OK;
+    }
     if (std::strcmp(name, "deterministic") == 0) {
         h->deterministic = value != 0;
         return PTYCHO_OK;
@@ -1034,7 +1101,7 @@ int ptycho_profile(ptycho_handle h, int enable) {
 int ptycho_profile_read(ptycho_handle h, double* ms, long long* launches, int n) {
     int rc = check_handle(h);
     if (rc) return rc;
-    if (!ms || !launches || n < K_COUNT) return fail(PTYCHO_ERR_ARG, "need arrays of at least 16 entries");
+    if (!ms || !launches || n < K_COUNT) return fail(PTYCHO_ERR_ARG, "need arrays of at least 18 entries");
     for (int i = 0; i < n; ++i) { ms[i] = 0.0; launches[i] = 0; }
     for (auto& sp : h->spans) {
         HIP_TRY(hipEventSynchronize(sp.b));

@@ -95,7 +95,8 @@ KERNEL_NAMES = ("k_cols<FWD>", "k_rows<fwd>", "k_rows<inv>", "k_cols<ADJ_OBJ>",
                 "k_cols<ADJ_PRB>", "k_cols<PLAIN>", "sort_positions",
                 "k_rows_fused<STATS>", "k_rows_fused<PROJECT>", "k_rows_fused<LINESEARCH>",
                 "k_cg_scalars", "k_fwd_fused256", "k_cg_update",
-                "k_rows_fused<CROSS>", "k_cols_argmax", "k_zoom_argmax")
+                "k_rows_fused<CROSS>", "k_cols_argmax", "k_zoom_argmax",
+                "k_fwd_tile", "k_adjprb_tile")
 last_error = _sig("ptycho_last_error", ctypes.c_char_p)
 version = _sig("ptycho_version", ctypes.c_char_p)
 

@@ -140,6 +140,11 @@ class PtychoHIP:
         """ndet = 256: split the DFT over y between the column and the row pass (default on)."""
         nat.check(nat.set_option(self._h, b"split", int(bool(on))))
 
+    def set_tile(self, on=True):
+        """ndet <= 128: forward operator and probe adjoint as one launch each, the tile stays in the compute unit's
+        LDS (default on); off = the two-pass kernels of the larger sizes."""
+        nat.check(nat.set_option(self._h, b"tile", int(bool(on))))
+
     def set_deterministic(self, on=True):
         """Adjoints accumulate in 64-bit fixed point (integer atomics): bitwise reproducible results
         (the reference's float ``atomicAdd``, kernels.cu:73-80,92-93, is not).  ndet <= 512."""

@@ -85,21 +85,48 @@ def test_fwd_adj_adjprobe_match_oracle(pt, ndet, nprb, ny, nx, step, ntheta):
         assert (slv.ptheta, slv.nz, slv.n, slv.nscan, slv.ndet, slv.nprb) == \
             (ntheta, p["nz"], p["n"], p["nscan"], ndet, nprb)
         psi, scan, prb = dev(p["psi"]), dev(p["scan"]), dev(p["probe"])
-        g = host(slv.fwd(psi, scan, prb))
-        want = op.fwd(p["psi"], p["scan"], p["probe"], ndet, "double")
-        e = err(g, want)
-        assert e[0] < REL_MAX and e[1] < REL_L2, ("fwd", e)
-        if p["nscan"] >= 4:
-            assert np.all(g[0, 1] == 0)    # skipped position -> exact zeros
-        y = (rng.standard_normal(g.shape) + 1j * rng.standard_normal(g.shape)).astype(np.complex64)
-        got = host(slv.adj(dev(y), scan, prb))
-        want = op.adj(y, p["scan"], p["probe"], p["nz"], p["n"], "double")
-        e = err(got, want)
-        assert e[0] < REL_MAX and e[1] < REL_L2, ("adj", e)
-        got = host(slv.adj_probe(dev(y), scan, psi))
-        want = op.adj_probe(y, p["scan"], p["psi"], nprb, "double")
-        e = err(got, want)
-        assert e[0] < REL_MAX and e[1] < REL_L2, ("adj_probe", e)
+        want_g = op.fwd(p["psi"], p["scan"], p["probe"], ndet, "double")
+        y = (rng.standard_normal(want_g.shape) + 1j * rng.standard_normal(want_g.shape)).astype(np.complex64)
+        want_a = op.adj(y, p["scan"], p["probe"], p["nz"], p["n"], "double")
+        want_p = op.adj_probe(y, p["scan"], p["psi"], nprb, "double")
+        # ndet <= 128 has two paths: one launch with the tile in LDS (default) and the two-pass kernels
+        for tile in ((True, False) if ndet <= 128 else (True,)):
+            slv.set_tile(tile)
+            g = host(slv.fwd(psi, scan, prb))
+            e = err(g, want_g)
+            assert e[0] < REL_MAX and e[1] < REL_L2, ("fwd", tile, e)
+            if p["nscan"] >= 4:
+                assert np.all(g[0, 1] == 0)    # skipped position -> exact zeros
+            e = err(host(slv.adj(dev(y), scan, prb)), want_a)
+            assert e[0] < REL_MAX and e[1] < REL_L2, ("adj", tile, e)
+            e = err(host(slv.adj_probe(dev(y), scan, psi)), want_p)
+            assert e[0] < REL_MAX and e[1] < REL_L2, ("adj_probe", tile, e)
+
+
+@pytest.mark.parametrize("ndet,nprb,ny,nx", [(16, 16, 151, 65), (32, 27, 67, 39), (64, 64, 41, 19), (128, 100, 17, 9)])
+def test_tile_kernels_equal_the_two_pass_kernels(pt, ndet, nprb, ny, nx):
+    """ndet <= 128, more positions than one trip of the persistent workgroups holds, a count that does not fill the last
+    workgroup, two angles (the probe adjoint's accumulators are flushed at the angle change), padded probes, skipped and
+    overhanging positions: the one-launch kernels (k_tile.hpp) against the two-pass kernels, which the oracle test above
+    checks on small cases."""
+    p = problem(ndet, nprb, ny, nx, 3, ntheta=2)
+    rng = np.random.default_rng(5)
+    ns = p["nscan"]
+    y = (rng.standard_normal((2, ns, ndet, ndet)) + 1j * rng.standard_normal((2, ns, ndet, ndet))).astype(np.complex64)
+    with pt.PtychoCuFFT(ns, nprb, ndet, 2, p["nz"], p["n"]) as slv:
+        psi, scan, prb, yd = dev(p["psi"]), dev(p["scan"]), dev(p["probe"]), dev(y)
+        slv.set_tile(False)
+        ref = [host(slv.fwd(psi, scan, prb)), host(slv.adj(yd, scan, prb)), host(slv.adj_probe(yd, scan, psi))]
+        slv.set_tile(True)
+        slv.profile(True)
+        got = [host(slv.fwd(psi, scan, prb)), host(slv.adj(yd, scan, prb)), host(slv.adj_probe(yd, scan, psi))]
+        ran = slv.profile_read()
+        slv.profile(False)
+    assert "k_fwd_tile" in ran and (ndet > 64 or "k_adjprb_tile" in ran), ran      # the path under test did run
+    for name, a, b in zip(("fwd", "adj", "adj_probe"), got, ref):
+        e = err(a, b.astype(np.complex128))
+        assert e[0] < 2e-5 and e[1] < 2e-6, (name, e)
+    assert np.all(got[0][0, 1] == 0)        # skipped position -> exact zeros
 
 
 def test_chunking_does_not_change_results(pt):
