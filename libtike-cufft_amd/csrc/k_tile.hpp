@@ -22,9 +22,6 @@
 // Tiles of 16^2 and 32^2 are packed 16 / 4 to a workgroup (256 threads).  Workgroups are persistent: position
 // p = blockIdx.x * TPW + w, stride gridDim.x * TPW.
 // ---------------------------------------------------------------------------
-#ifndef PTY_TILE_GB
-#define PTY_TILE_GB 4
-#endif
 template <int N>
 struct TileCfg {
     static constexpr int T = Plan<N>::T;
@@ -131,6 +128,80 @@ __device__ __forceinline__ void tile_patch(const c32* __restrict__ ft, const Pos
     }
 }
 
+// The same for tiles whose lanes of a wave share j0 (ndet >= 64: a wave is 64 consecutive columns of one j0; `j0u` comes
+// from readfirstlane): the row index, its clamp, the row weights and the two row pointers of every m are wave-uniform
+// and live in scalar registers / run on the scalar unit; a lane contributes its two clamped column offsets and column
+// weights, computed once.  Per m: four loads with a scalar base, five packed multiply-adds.
+template <class P, int BATCH, class Fn>
+__device__ __forceinline__ void tile_patch_rows(const c32* __restrict__ ft, const Pos& q, const Geom& ge, int j0u, int ix, bool col_ok, Fn fn) {
+    constexpr int E = P::E, T = P::T;
+    const int X = q.sx + ix;
+    const unsigned X0 = (unsigned)(X < 0 ? 0 : (X >= ge.n ? ge.n - 1 : X)), X1 = (unsigned)(X + 1 < 0 ? 0 : (X + 1 >= ge.n ? ge.n - 1 : X + 1));
+    const float ax = (col_ok && X >= 0 && X < ge.n) ? 1.0f - q.fx : 0.0f, bx = (col_ok && X + 1 >= 0 && X + 1 < ge.n) ? q.fx : 0.0f;
+    const float wy0 = 1.0f - q.fy, wy1 = q.fy;
+#pragma unroll
+    for (int m = 0; m < E; ++m) {
+        const int iy = j0u + m * T - ge.pad;
+        const bool rowok = iy >= 0 && iy < ge.nprb;
+        const int Y = q.sy + iy;
+        const int Y0 = Y < 0 ? 0 : (Y >= ge.nz ? ge.nz - 1 : Y), Y1 = Y + 1 < 0 ? 0 : (Y + 1 >= ge.nz ? ge.nz - 1 : Y + 1);
+        const float ay = (rowok && Y >= 0 && Y < ge.nz) ? wy0 : 0.0f, by = (rowok && Y + 1 >= 0 && Y + 1 < ge.nz) ? wy1 : 0.0f;
+        const c32* r0 = ft + (unsigned)(Y0 * ge.n);
+        const c32* r1 = ft + (unsigned)(Y1 * ge.n);
+        fn(m, rowok && col_ok, (r0[X0] * ax + r0[X1] * bx) * ay + (r1[X0] * ax + r1[X1] * bx) * by);
+        if (m % BATCH == BATCH - 1) __builtin_amdgcn_sched_barrier(0);
+    }
+}
+template <int N, int BATCH, class Fn>
+__device__ __forceinline__ void tile_exit_taps(const c32* __restrict__ ft, const Pos& q, const Geom& ge, int j0, int ix, bool col_ok, Fn fn) {
+    if constexpr (TileCfg<N>::NL >= 64) tile_patch_rows<Plan<N>, BATCH>(ft, q, ge, uni_i(j0), ix, col_ok, fn);
+    else tile_patch<Plan<N>, BATCH>(ft, q, ge, j0, ix, col_ok, fn);
+}
+
+// Exit wave of the 16 CONSECUTIVE rows 16 jb ... 16 jb + 15 of detector column c (kernels.cu:95-107): every object element
+// is requested ONCE per position -- 17 rows of 16 bytes (elements X, X + 1) per thread; the row-pair sums h = f[X] (1-fx) +
+// f[X+1] fx are shared by the two probe rows that tap them -- instead of four 8-byte taps per probe pixel (64 requests per
+// thread: an ablation put that gather at half of the forward tile kernel's time, 0.14 of 0.28 ms at 4096 x 128^2).
+// Elements outside the object enter as zero, probe padding gives zero (as tile_patch).  ex[k] <-> row 16 jb + k.
+typedef float f32x4_a8 __attribute__((ext_vector_type(4), aligned(8)));
+template <int N>
+__device__ __forceinline__ void tile_exit_block(const c32* __restrict__ ft, const c32* __restrict__ prb, const Pos& q, const Geom& ge,
+                                                int jb, int ix, bool col_ok, float cinv, c32* ex) {
+    constexpr int E = Plan<N>::E;
+    const c32 zero = c32{0.0f, 0.0f};
+    const int X = q.sx + ix;
+    const int Xb = X < 0 ? 0 : (X > ge.n - 2 ? ge.n - 2 : X);   // the 16 bytes [Xb, Xb + 1] lie inside the row
+    const int sel = X - Xb;                                      // 0 except where the patch leaves the object sideways
+    const float fx0 = (col_ok && X >= 0 && X < ge.n) ? 1.0f - q.fx : 0.0f;       // weight of element X
+    const float fx1 = (col_ok && X + 1 >= 0 && X + 1 < ge.n) ? q.fx : 0.0f;      // weight of element X + 1
+    const float wa = sel == 0 ? fx0 : (sel == -1 ? fx1 : 0.0f);   // weight of the first loaded element  (it is X, or X + 1 when X = -1)
+    const float wb = sel == 0 ? fx1 : (sel == 1 ? fx0 : 0.0f);    // weight of the second loaded element (it is X + 1, or X when X = n - 1)
+    const float wy0 = 1.0f - q.fy, wy1 = q.fy;
+    const int r0 = E * jb - ge.pad;   // probe row of k = 0
+    c32 hprev = zero;
+#pragma unroll
+    for (int k = 0; k <= E; ++k) {
+        const int Y = q.sy + r0 + k;
+        const int Yc = Y < 0 ? 0 : (Y >= ge.nz ? ge.nz - 1 : Y);
+        const f32x4_a8 e = *reinterpret_cast<const f32x4_a8*>(ft + (unsigned)(Yc * ge.n + Xb));
+        // (no selects on loaded values and no conditional loads: a select turns into a branch around the load, and the
+        // branches pinned every request behind the previous one's wait -- 34 L2 round trips per position)
+        const bool yin = Y >= 0 && Y < ge.nz;
+        const c32 h = c32{e.x, e.y} * (yin ? wa : 0.0f) + c32{e.z, e.w} * (yin ? wb : 0.0f);
+        if (k > 0) {
+            const int iy = r0 + k - 1;
+            const bool ok = col_ok && iy >= 0 && iy < ge.nprb;
+            const c32 pv = prb[ok ? iy * ge.nprb + ix : 0];
+            ex[k - 1] = cmul(pv * (ok ? cinv : 0.0f), hprev * wy0 + h * wy1);
+        }
+        hprev = h;
+        // rows requested together: two batches at ndet >= 64 (0.233 -> 0.217 ms at 128, 0.052 -> 0.046 at 64), batches of four
+        // below (per-lane row arithmetic: larger batches take 200+ registers there)
+        constexpr int RB = N >= 64 ? 9 : 4;
+        if (k % RB == RB - 1) __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 // position of a tile slot; for whole-wave tiles the decoded position is moved to scalar registers
 template <int N>
 __device__ __forceinline__ Pos tile_pos(const float* __restrict__ scan, int p, const Geom& ge) {
@@ -157,7 +228,6 @@ __global__ __launch_bounds__(TileCfg<N>::NT) void k_fwd_tile(const TileArgs a) {
     const Geom ge = a.ge;
     const float cinv = 1.0f / (float)N;   // kernels.cu:65
     const c32 zero = c32{0.0f, 0.0f};
-    constexpr int GB = PTY_TILE_GB;   // rows of object taps requested together
     for (int i = tid; i < N; i += CF::NT) wtab[i] = a.table[i];
     __syncthreads();
 
@@ -168,26 +238,25 @@ __global__ __launch_bounds__(TileCfg<N>::NT) void k_fwd_tile(const TileArgs a) {
         const Pos q = tile_pos<N>(a.scan, p, ge);
         const c32* ft = a.obj + (size_t)th * ge.nz * ge.n;
         c32 v[CPT][E];
-        // ---- exit waves of the thread's columns (kernels.cu:95-107), straight into the registers of the DFT over y ----
+        // ---- exit waves of the thread's columns (kernels.cu:95-107): blocks of 16 consecutive rows -> tile -> DFT over y ----
         // (gathering the NEXT position's exit wave while this tile streams out was measured slower: 0.290 against
         // 0.274 ms at ndet = 128, 0.075 against 0.057 ms at 64 -- the 32 carried registers cost a wave per SIMD)
 #pragma unroll
         for (int h = 0; h < CPT; ++h) {
-            const int ix = c + h * NL - ge.pad;
+            const int l = c + h * NL, ix = l - ge.pad;
             const bool col_ok = ix >= 0 && ix < ge.nprb;
-            const c32* prb = a.prb + (size_t)th * ge.nprb * ge.nprb;
-            const int poff = (j0 - ge.pad) * ge.nprb + ix;   // this thread's pixel of row m = 0
-            c32 nat[E];
+            c32 ex[E];
+            if (q.valid) {
+                tile_exit_block<N>(ft, a.prb + (size_t)th * ge.nprb * ge.nprb, q, ge, NL >= 64 ? uni_i(j0) : j0, ix, col_ok, cinv, ex);
+            } else {
 #pragma unroll
-            for (int m = 0; m < E; ++m) nat[m] = zero;
-            if (q.valid)
-                tile_patch<P, GB>(ft, q, ge, j0, ix, col_ok, [&](int m, bool ok, c32 val) {
-                    const c32 pv = prb[ok ? poff + m * T * ge.nprb : 0];
-                    nat[m] = ok ? cmul(pv * cinv, val) : zero;
-                });
-            F::from_natural(nat, v[h]);
+                for (int k = 0; k < E; ++k) ex[k] = zero;
+            }
+#pragma unroll
+            for (int k = 0; k < E; ++k) tile[(E * j0 + k) * LS + l] = ex[k];
         }
-        tile_dft<N, -1, false, false>(v, tile, wtab, c, j0);
+        __syncthreads();
+        tile_dft<N, -1, false, true>(v, tile, wtab, c, j0);
         if (P::NSTEP > 1) __syncthreads();   // the exchange slots have been read: the tile may take the column results
         tile_put<N, -1, false>(v, tile, c, j0);   // [ky][x]
         __syncthreads();
@@ -290,8 +359,12 @@ __global__ __launch_bounds__(TileCfg<N>::NT) void k_adjprb_tile(const TileArgs a
                 const bool col_ok = ix >= 0 && ix < ge.nprb;
                 c32 nat[E];
                 F::to_natural(v[h], nat);
-                tile_patch<P, 4>(ft, q, ge, j0, ix, col_ok, [&](int m, bool ok, c32 val) {
-                    if (ok) acc[h][m] += cmulc(nat[m], val);
+                // (unconditional: the patch value is an exact zero wherever the probe has no pixel -- its weights are zero
+                // there --, and an `if (ok)` becomes a branch that pins each row's four requests behind the previous row's wait)
+                // (packed tiles, ndet <= 32, keep the branch: without it the per-lane row arithmetic of all 16 rows is hoisted and
+                // the kernel takes 255 registers, 0.136 against 0.093 ms at 16384 x 32^2)
+                tile_exit_taps<N, 4>(ft, q, ge, j0, ix, col_ok, [&](int m, bool ok, c32 val) {
+                    if (NL >= 64 || ok) acc[h][m] += cmulc(nat[m], val);
                 });
             }
         }
@@ -308,7 +381,9 @@ __global__ __launch_bounds__(TileCfg<N>::NT) void k_adjprb_tile(const TileArgs a
 #pragma unroll
             for (int m = 0; m < E; ++m) {
                 c32 sum = zero;
+#pragma unroll 4
                 for (int ww = 0; ww < TPW; ++ww) sum += lds[(ww * E + m) * TT + t];
+                __builtin_amdgcn_sched_barrier(0);   // (unrolled and hoisted, the 16 x 16 reads took 256 registers)
                 acc[0][m] = sum;
             }
             flush(0);

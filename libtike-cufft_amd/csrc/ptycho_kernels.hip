@@ -389,7 +389,7 @@ int do_fwd(ptycho_handle h, c32* g, const c32* f, const float* scan, const c32* 
     int rc = PTYCHO_OK;
     if constexpr (N <= 128) {
         // the tile fits one CU's LDS: one launch, no intermediate in HBM, no position sort (16-byte rows of g)
-        if (h->use_tile && ((size_t)g % 16) == 0 && (long long)ge.nz * ge.n < (1ll << 28)) return launch_fwd_tile<N>(h, g, f, scan, prb, st);
+        if (h->use_tile && ((size_t)g % 16) == 0 && ge.n >= 2 && (long long)ge.nz * ge.n < (1ll << 28)) return launch_fwd_tile<N>(h, g, f, scan, prb, st);
     }
 #ifdef PTYCHO_EXPERIMENTS
     if constexpr (N == 256) {
@@ -491,8 +491,7 @@ int do_adj(ptycho_handle h, c32* f, const c32* g, const float* scan, c32* prb, i
     const bool window = flg == 0 && h->use_window && WinCfg<N>::fits;
     if constexpr (N <= 128) {
         // probe adjoint with the tile in LDS: one launch, g read once, no scratch, no position sort
-        // (at ndet = 128 the 16 accumulators per thread do not fit 128 registers next to the transforms: 0.48 against 0.45 ms)
-        if (N <= 64 && flg == 1 && h->use_tile && !h->deterministic && ((size_t)g % 16) == 0 && (long long)ge.nz * ge.n < (1ll << 28))
+        if (flg == 1 && h->use_tile && !h->deterministic && ((size_t)g % 16) == 0 && (long long)ge.nz * ge.n < (1ll << 28))
             return launch_adjprb_tile<N>(h, prb, g, scan, f, st);
     }
     // positions are visited in sorted order (angle, column bucket, row): neighbours in the
@@ -515,8 +514,8 @@ int do_adj(ptycho_handle h, c32* f, const c32* g, const float* scan, c32* prb, i
         if constexpr (N == 256) {
             if (split) rc = launch_rows_split<N, +1>(h, ra, st);
         }
-        if constexpr (N <= 64) {
-            // whole tiles through LDS, 16 bytes per lane (k_tile.hpp): 0.34 -> 0.06 ms at 16384 x 32^2
+        if constexpr (N <= 128) {
+            // whole tiles through LDS, 16 bytes per lane (k_tile.hpp): 0.34 -> 0.047 ms at 16384 x 32^2
             tiled = h->use_tile && ((size_t)g % 16) == 0;
             if (tiled) {
                 ProfSpan ps(h, K_ROWS_INV, st);
