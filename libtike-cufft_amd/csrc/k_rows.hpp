@@ -163,6 +163,18 @@ __global__ __launch_bounds__(256) void k_rows_split(const RowArgs a) {
 __device__ __forceinline__ float fsqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
 __device__ __forceinline__ float frcp(float x) { return __builtin_amdgcn_rcpf(x); }
 
+// An unconditional global load whose value is masked afterwards (m = all ones or zero, made opaque by the caller so that the
+// AND does not turn back into a select).  `pred ? load(p) : zero` puts every request into a branch of its own
+// (s_and_saveexec / s_cbranch_execz), and the branches pin each request behind the previous one's wait: the fused row
+// stages showed 50-100 branches and at most 2-4 requests in flight per thread.
+__device__ __forceinline__ c32 load_masked(const c32* __restrict__ p, unsigned m) {
+    const c32 val = __builtin_nontemporal_load(p);
+    return c32{__uint_as_float(__float_as_uint(val.x) & m), __uint_as_float(__float_as_uint(val.y) & m)};
+}
+__device__ __forceinline__ float load_masked(const float* __restrict__ p, unsigned m) {
+    return __uint_as_float(__float_as_uint(__builtin_nontemporal_load(p)) & m);
+}
+
 enum RowEp { EP_STATS = 1, EP_PROJECT = 2, EP_LINESEARCH = 3, EP_CROSS = 6, EP_LINESEARCH_M = 7, EP_STATS_M = 8 };
 constexpr int kMaxModes = 8;   // EP_LINESEARCH_M: slot pairs (2k, 2k+1), k < nmodes
 constexpr int kMaxCand = 16;
@@ -268,7 +280,8 @@ constexpr int fused_min_waves() {
 template <>
 constexpr int fused_min_waves<256, EP_STATS>() { return 4;   // 0.527 -> 0.505 ms (PROJECT at three waves spills: 1.03 -> 1.31)
 }
-template <int N, int EP>
+// FW: the launch covers the full width (xa = 0, xb = N -- the probe fills the detector): no column predicate, loads unconditional
+template <int N, int EP, bool FW = false>
 __global__ __launch_bounds__(256, (fused_min_waves<N, EP>())) void k_rows_fused(const RowFusedArgs a) {
     using P = Plan<N>;
     using F = Fft<P, -1>;
@@ -379,14 +392,20 @@ __global__ __launch_bounds__(256, (fused_min_waves<N, EP>())) void k_rows_fused(
         // loads / stores take the saddr form and no 64-bit address lives in a VGPR
         const size_t boff = (size_t)batch * B * N;
         const unsigned fN = (unsigned)(f * N);
+        const unsigned fNs = ok ? fN : 0u;   // FW: a row past the end reads row 0 of its batch (always there) ...
+        unsigned rowm = ok ? 0xffffffffu : 0u;   // ... and masks it
+        if constexpr (FW) asm volatile("" : "+v"(rowm));
         c32 v[E], g1[E];
         const c32* __restrict__ first_src = (EP == EP_LINESEARCH_M || EP == EP_STATS_M) ? a.sm[0] : a.s1;
-        fft.template load<0>(v, j0, [&](int i) { return (ok && i >= a.xa && i < a.xb) ? __builtin_nontemporal_load(first_src + boff + (fN + (unsigned)i)) : zero; });
+        fft.template load<0>(v, j0, [&](int i) { if constexpr (FW) return load_masked(first_src + boff + (fNs + (unsigned)i), rowm); else return (ok && i >= a.xa && i < a.xb) ? __builtin_nontemporal_load(first_src + boff + (fN + (unsigned)i)) : zero; });
         fwd_row(v, g1);
         float d[E];
         auto load_data = [&]() {
 #pragma unroll
-            for (int m = 0; m < E; ++m) d[m] = ok ? __builtin_nontemporal_load(a.data + boff + (fN + (unsigned)(j0 + m * T))) : 0.0f;
+            for (int m = 0; m < E; ++m) {
+                if constexpr (FW) d[m] = load_masked(a.data + boff + (fNs + (unsigned)(j0 + m * T)), rowm);
+                else d[m] = ok ? __builtin_nontemporal_load(a.data + boff + (fN + (unsigned)(j0 + m * T))) : 0.0f;
+            }
         };
         if (EP == EP_STATS || EP == EP_PROJECT) load_data();
         if (EP == EP_CROSS) {
@@ -398,7 +417,7 @@ __global__ __launch_bounds__(256, (fused_min_waves<N, EP>())) void k_rows_fused(
             // kernel then fits 256 VGPRs and two waves per SIMD instead of one
 #pragma unroll
             for (int m = 0; m < E; ++m) stash[m * 256 + tid] = g1[m];
-            fft.template load<0>(v, j0, [&](int i) { return (ok && i >= a.xa && i < a.xb) ? __builtin_nontemporal_load(a.s2 + boff + (fN + (unsigned)i)) : zero; });
+            fft.template load<0>(v, j0, [&](int i) { if constexpr (FW) return load_masked(a.s2 + boff + (fNs + (unsigned)i), rowm); else return (ok && i >= a.xa && i < a.xb) ? __builtin_nontemporal_load(a.s2 + boff + (fN + (unsigned)i)) : zero; });
             fwd_row(v, g2);
 #pragma unroll
             for (int m = 0; m < E; ++m) g1[m] = stash[m * 256 + tid];
@@ -448,7 +467,7 @@ __global__ __launch_bounds__(256, (fused_min_waves<N, EP>())) void k_rows_fused(
             for (int m = 0; m < E; ++m) I[m] = g1[m].x * g1[m].x + g1[m].y * g1[m].y;
             for (int k = 1; k < a.nmodes; ++k) {
                 const c32* __restrict__ src = a.sm[k];
-                fft.template load<0>(v, j0, [&](int i) { return (ok && i >= a.xa && i < a.xb) ? __builtin_nontemporal_load(src + boff + (fN + (unsigned)i)) : zero; });
+                fft.template load<0>(v, j0, [&](int i) { if constexpr (FW) return load_masked(src + boff + (fNs + (unsigned)i), rowm); else return (ok && i >= a.xa && i < a.xb) ? __builtin_nontemporal_load(src + boff + (fN + (unsigned)i)) : zero; });
                 fwd_row(v, g1);
 #pragma unroll
                 for (int m = 0; m < E; ++m) I[m] += g1[m].x * g1[m].x + g1[m].y * g1[m].y;
@@ -515,14 +534,14 @@ __global__ __launch_bounds__(256, (fused_min_waves<N, EP>())) void k_rows_fused(
             for (int k = 0; k < a.nmodes; ++k) {
                 if (k > 0) {
                     const c32* __restrict__ src1 = a.sm[2 * k];
-                    fft.template load<0>(v, j0, [&](int i) { return (ok && i >= a.xa && i < a.xb) ? __builtin_nontemporal_load(src1 + boff + (fN + (unsigned)i)) : zero; });
+                    fft.template load<0>(v, j0, [&](int i) { if constexpr (FW) return load_masked(src1 + boff + (fNs + (unsigned)i), rowm); else return (ok && i >= a.xa && i < a.xb) ? __builtin_nontemporal_load(src1 + boff + (fN + (unsigned)i)) : zero; });
                     fwd_row(v, g1);
                 }
 #pragma unroll
                 for (int m = 0; m < E; ++m) stash[m * 256 + tid] = g1[m];   // t1 waits in LDS (private slots)
                 const c32* __restrict__ src2 = a.sm[2 * k + 1];
                 c32 g2[E];
-                fft.template load<0>(v, j0, [&](int i) { return (ok && i >= a.xa && i < a.xb) ? __builtin_nontemporal_load(src2 + boff + (fN + (unsigned)i)) : zero; });
+                fft.template load<0>(v, j0, [&](int i) { if constexpr (FW) return load_masked(src2 + boff + (fNs + (unsigned)i), rowm); else return (ok && i >= a.xa && i < a.xb) ? __builtin_nontemporal_load(src2 + boff + (fN + (unsigned)i)) : zero; });
                 fwd_row(v, g2);
 #pragma unroll
                 for (int m = 0; m < E; ++m) {
@@ -559,7 +578,7 @@ __global__ __launch_bounds__(256, (fused_min_waves<N, EP>())) void k_rows_fused(
             }
         } else {   // EP_LINESEARCH
             c32 g2[E];
-            fft.template load<0>(v, j0, [&](int i) { return (ok && i >= a.xa && i < a.xb) ? __builtin_nontemporal_load(a.s2 + boff + (fN + (unsigned)i)) : zero; });
+            fft.template load<0>(v, j0, [&](int i) { if constexpr (FW) return load_masked(a.s2 + boff + (fNs + (unsigned)i), rowm); else return (ok && i >= a.xa && i < a.xb) ? __builtin_nontemporal_load(a.s2 + boff + (fN + (unsigned)i)) : zero; });
             fwd_row(v, g2);
             load_data();   // after the second transform: keeps 16 registers free during it
             // two detector pixels per step in packed float32 (v_pk_fma_f32 / v_pk_add_f32), four

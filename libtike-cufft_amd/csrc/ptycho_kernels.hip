@@ -706,7 +706,8 @@ int do_cg_rows(ptycho_handle h, RowFusedArgs a, hipStream_t st) {
     a.fold = h->fold;
     {
         ProfSpan ps(h, (EP == EP_STATS || EP == EP_STATS_M) ? K_ROWS_STATS : EP == EP_PROJECT ? K_ROWS_PROJECT : (EP == EP_LINESEARCH || EP == EP_LINESEARCH_M) ? K_ROWS_LINESEARCH : K_ROWS_CROSS, st);
-        hipLaunchKernelGGL((k_rows_fused<N, EP>), dim3((unsigned)grid), dim3(256), 0, st, a);
+        if (a.xa == 0 && a.xb == N) hipLaunchKernelGGL((k_rows_fused<N, EP, true>), dim3((unsigned)grid), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((k_rows_fused<N, EP, false>), dim3((unsigned)grid), dim3(256), 0, st, a);
     }
     HIP_TRY(hipGetLastError());
     return PTYCHO_OK;
