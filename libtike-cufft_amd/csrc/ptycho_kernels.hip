@@ -279,7 +279,10 @@ int launch_rows(ptycho_handle h, RowArgs a, hipStream_t st) {
     a.nt = nt_mode;
     {
         ProfSpan ps(h, DIR < 0 ? K_ROWS_FWD : K_ROWS_INV, st);
-        hipLaunchKernelGGL((k_rows<N, DIR>), dim3((unsigned)grid), dim3(256), 0, st, a);
+        if (a.xa == 0 && a.wa == 0 && a.xb == N && a.wb == N && a.nrows % B == 0)
+            hipLaunchKernelGGL((k_rows<N, DIR, true>), dim3((unsigned)grid), dim3(256), 0, st, a);
+        else
+            hipLaunchKernelGGL((k_rows<N, DIR, false>), dim3((unsigned)grid), dim3(256), 0, st, a);
     }
     HIP_TRY(hipGetLastError());
     return PTYCHO_OK;
