@@ -15,11 +15,15 @@ slv = pt.CGPtychoSolver(4096, ndet, ndet, 1, p["nz"], p["n"]); slv.verbose = Fal
 data = (torch.abs(slv.fwd(psi, scan, prb)) ** 2).contiguous()
 for rec in (False, True):
     slv.run(data, torch.ones_like(psi), scan.clone(), prb[:, None].clone(), piter=10, recover_prb=rec); torch.cuda.synchronize()
+    t = time.perf_counter()
+    slv.run(data, torch.ones_like(psi), scan.clone(), prb[:, None].clone(), piter=50, recover_prb=rec); torch.cuda.synchronize()
+    dt = (time.perf_counter() - t) / 50
+    print("ndet %d, 4096 positions, recover_prb=%s: %.3f ms/iter (%.1f it/s) without the in-library profiler" % (ndet, rec, dt * 1e3, 1 / dt))
     slv.profile(True)
     t = time.perf_counter()
     slv.run(data, torch.ones_like(psi), scan.clone(), prb[:, None].clone(), piter=30, recover_prb=rec); torch.cuda.synchronize()
     dt = (time.perf_counter() - t) / 30
     prof = slv.profile_read(); slv.profile(False)
-    print("ndet %d, 4096 positions, recover_prb=%s: %.3f ms/iter (%.1f it/s)" % (ndet, rec, dt * 1e3, 1 / dt))
+    print("   with an event pair around every launch: %.3f ms/iter; per kernel:" % (dt * 1e3))
     for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0]):
         print("   %-28s %7.3f ms/iter %5.1f launches/iter %.3f each" % (k, v[0] / 30, v[1] / 30, v[0] / v[1]))
