@@ -210,7 +210,9 @@ int launch_adjwin(ptycho_handle h, ColArgs a, hipStream_t st, int wg_target = 0)
     const int np = a.k_end - a.k_begin;
     if (np <= 0 || a.nstrips <= 0) return PTYCHO_OK;
     // contiguous runs of the sorted order; about 4 workgroups per CU in total
-    if (wg_target <= 0) wg_target = h->n_cu * 4;   // (two rounds; one round of runs of 128: within 1 %, six or eight rounds: +4 %)
+    // ndet 256: two rounds of resident workgroups (one round of runs of 128: within 1 %, six or eight rounds: +4 %);
+    // ndet 128: ONE round (two workgroups per CU, runs of 32 positions): 0.234 -> 0.197 ms at 4096 x 128^2; 64 and 32: no gain / worse
+    if (wg_target <= 0) wg_target = h->n_cu * (N == 128 ? 2 : 4);
     int nseg = (wg_target + a.nstrips - 1) / a.nstrips;
     if (nseg < 1) nseg = 1;
     int seglen = (np + nseg - 1) / nseg;
