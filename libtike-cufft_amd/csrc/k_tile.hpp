@@ -14,8 +14,9 @@
 //   column role: column x = l, points y = j0 + b T + t N/R of the DFT over y   (LDS image [y][x]: lanes contiguous)
 //   row role   : row   y = l, points x = j0 + b T + t N/R of the DFT over x   (lanes stride LS = N + 1 elements:
 //                an odd stride, so the 32 lanes of a half-wave hit 32 different bank pairs)
-//   fwd   (ptychofft.cu:60-73, kernels.cu:95-107): gather (4 taps from the object, L2) x c*probe -> DFT over y
-//          -> tile -> DFT over x -> tile -> 16 bytes per lane, whole rows, nontemporal, to g
+//   fwd   (ptychofft.cu:60-73, kernels.cu:95-107): exit wave of 16 consecutive rows per thread (tile_exit_block: every
+//          object element requested once, L2) x c*probe -> tile -> DFT over y -> tile -> DFT over x -> tile -> 16 bytes
+//          per lane, whole rows, nontemporal, to g
 //   adj_probe (ptychofft.cu:76-88 flg 1, kernels.cu:82-94): g -> tile (16 bytes per lane) -> IDFT over x -> IDFT
 //          over y -> acc += near * conj(bilerp(psi)) in registers over all positions of the workgroup -> one float
 //          atomic pair per probe pixel and workgroup at the end
@@ -218,8 +219,7 @@ template <int N>
 __global__ __launch_bounds__(TileCfg<N>::NT) void k_fwd_tile(const TileArgs a) {
     using CF = TileCfg<N>;
     using P = Plan<N>;
-    using F = Fft<P, -1>;
-    constexpr int E = P::E, T = P::T, TT = CF::TT, TPW = CF::TPW, LS = CF::LS, CPT = CF::CPT, NL = CF::NL;
+    constexpr int E = P::E, TT = CF::TT, TPW = CF::TPW, LS = CF::LS, CPT = CF::CPT, NL = CF::NL;
     __shared__ c32 lds[TPW * N * LS];
     __shared__ c32 wtab[N];
     const int tid = threadIdx.x, w = tid / TT, t = tid % TT;
@@ -239,8 +239,9 @@ __global__ __launch_bounds__(TileCfg<N>::NT) void k_fwd_tile(const TileArgs a) {
         const c32* ft = a.obj + (size_t)th * ge.nz * ge.n;
         c32 v[CPT][E];
         // ---- exit waves of the thread's columns (kernels.cu:95-107): blocks of 16 consecutive rows -> tile -> DFT over y ----
-        // (gathering the NEXT position's exit wave while this tile streams out was measured slower: 0.290 against
-        // 0.274 ms at ndet = 128, 0.075 against 0.057 ms at 64 -- the 32 carried registers cost a wave per SIMD)
+        // (requesting the NEXT position's rows before this tile streams out and finishing them afterwards was measured
+        // slower, twice: 0.322 against 0.217 ms at ndet = 128, 0.070 against 0.046 ms at 64 -- 68 registers of raw rows or 32 of
+        // finished values carried across the copy-out cost spills / a wave per SIMD; profiles/r03/knob_sweep.txt)
 #pragma unroll
         for (int h = 0; h < CPT; ++h) {
             const int l = c + h * NL, ix = l - ge.pad;
