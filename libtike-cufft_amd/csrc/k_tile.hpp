@@ -397,8 +397,9 @@ __global__ __launch_bounds__(TileCfg<N>::NT) void k_adjprb_tile(const TileArgs a
 // Row pass of the object adjoint for small tiles (ndet <= 64): dst tile j <- DFT over x of src tile tile_index[j], whole
 // rows in and out at 16 bytes per lane through the LDS tile.  (k_rows reads a row as T = ndet / 16 lanes x 16 strided
 // points: at ndet = 32 a wave instruction touches 64 separate 8-byte pieces and the pass runs at 0.8 TB/s.)
-template <int N, int DIR>
-__global__ __launch_bounds__(TileCfg<N>::NT) void k_rows_tile(const c32* __restrict__ src, c32* __restrict__ dst,
+// COLS: the DFT over y follows in the same launch (ptycho_fft2 of ndet <= 128: the whole 2-D transform of a tile)
+template <int N, int DIR, bool COLS = false>
+__global__ __launch_bounds__(TileCfg<N>::NT) void k_rows_tile(const c32* src, c32* dst,   // (may alias: ptycho_fft2 in place)
                                                               const int* __restrict__ tile_index, const int ntiles,
                                                               const c32* __restrict__ table) {
     using CF = TileCfg<N>;
@@ -428,6 +429,12 @@ __global__ __launch_bounds__(TileCfg<N>::NT) void k_rows_tile(const c32* __restr
         if (P::NSTEP > 1) __syncthreads();
         tile_put<N, DIR, true>(v, tile, c, j0);
         __syncthreads();
+        if constexpr (COLS) {
+            tile_dft<N, DIR, false, true>(v, tile, wtab, c, j0);
+            if (P::NSTEP > 1) __syncthreads();
+            tile_put<N, DIR, false>(v, tile, c, j0);
+            __syncthreads();
+        }
         if (live) {
             f32x4* out = reinterpret_cast<f32x4*>(dst + (size_t)j * N * N);
 #pragma unroll 4

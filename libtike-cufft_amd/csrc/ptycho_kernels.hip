@@ -572,6 +572,20 @@ int do_adj(ptycho_handle h, c32* f, const c32* g, const float* scan, c32* prb, i
 template <int N>
 int do_fft2(ptycho_handle h, c32* dst, const c32* src, long long nbatch, int dir, hipStream_t st) {
     constexpr int C = ColCfg<N>::C;
+    if constexpr (N <= 128) {
+        // the tile fits one CU's LDS: both passes in one launch (k_tile.hpp)
+        if (h->use_tile && ((size_t)src % 16) == 0 && ((size_t)dst % 16) == 0 && nbatch < (1ll << 30)) {
+            ProfSpan ps(h, K_COLS_PLAIN, st);
+            if (dir < 0)
+                hipLaunchKernelGGL((k_rows_tile<N, -1, true>), dim3(tile_grid<N>(h, nbatch)), dim3(TileCfg<N>::NT), 0, st, src, dst,
+                                   (const int*)nullptr, (int)nbatch, (const c32*)h->table);
+            else
+                hipLaunchKernelGGL((k_rows_tile<N, +1, true>), dim3(tile_grid<N>(h, nbatch)), dim3(TileCfg<N>::NT), 0, st, src, dst,
+                                   (const int*)nullptr, (int)nbatch, (const c32*)h->table);
+            HIP_TRY(hipGetLastError());
+            return PTYCHO_OK;
+        }
+    }
     RowArgs ra{};
     ra.src = src; ra.dst = dst; ra.table = h->table; ra.nrows = nbatch * N; ra.tile_index = nullptr;
     ra.xa = 0; ra.xb = N; ra.wa = 0; ra.wb = N;

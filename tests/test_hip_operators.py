@@ -249,17 +249,20 @@ def test_deterministic_adjoints_at_a_size_that_is_not_a_power_of_two(pt):
 
 def test_fft2_matches_numpy(pt):
     rng = np.random.default_rng(0)
-    for ndet in (16, 32, 64, 128, 256, 512, 1024, 2048):
-        nb = 3
+    # ndet <= 128: one launch with the tile in LDS (default) and the two-pass kernels; 1100 tiles of 64^2 are more than one
+    # trip of the persistent workgroups
+    for ndet, nb, tile in [(n, 3, True) for n in (16, 32, 64, 128, 256, 512, 1024, 2048)] + \
+                          [(n, 3, False) for n in (16, 32, 64, 128)] + [(64, 1100, True), (16, 37, True)]:
         x = (rng.standard_normal((nb, ndet, ndet)) + 1j * rng.standard_normal((nb, ndet, ndet))).astype(np.complex64)
         with pt.PtychoCuFFT(1, ndet, ndet, 1, ndet + 2, ndet + 2) as slv:
+            slv.set_tile(tile)
             f = host(slv.fft2(dev(x)))
             b = host(slv.fft2(dev(x), inverse=True))
             xd = dev(x)
             inplace = host(slv.fft2(xd, out=xd))
         wf = np.fft.fft2(x.astype(np.complex128))
         wb = np.fft.ifft2(x.astype(np.complex128)) * ndet * ndet
-        assert err(f, wf)[1] < REL_L2 and err(b, wb)[1] < REL_L2, ndet
+        assert err(f, wf)[1] < REL_L2 and err(b, wb)[1] < REL_L2, (ndet, nb, tile)
         np.testing.assert_array_equal(inplace, f)
 
 
