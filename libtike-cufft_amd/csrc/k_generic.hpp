@@ -47,13 +47,10 @@ __global__ __launch_bounds__(256) void k_lines_bluestein(const LineArgs a) {
         const c32* sl = a.src + (size_t)stile * a.n * a.n + off;
         c32* dl = a.dst + (size_t)tile * a.n * a.n + off;
         c32 v[E], nat[E];
-        // (no branch per point: a padding point reads point 0 of its line and enters with a zero chirp factor -- with
-        // `if (i >= n) return zero` every request sat in a branch of its own and waited for the previous one)
         fft.template load<0>(v, j0, [&](int i) {
-            const bool in = ok && i < a.n;
-            const int ic = in ? i : 0;
-            const c32 b = a.chirp[ic] * (in ? 1.0f : 0.0f);
-            return DIR < 0 ? cmul(sl[(size_t)ic * a.es], b) : cmulc(sl[(size_t)ic * a.es], b);
+            if (!(ok && i < a.n)) return zero;
+            const c32 b = a.chirp[i];
+            return DIR < 0 ? cmul(sl[(size_t)i * a.es], b) : cmulc(sl[(size_t)i * a.es], b);
         });
         // forward M-point FFT
         fft.template compute<0>(v);
@@ -94,10 +91,10 @@ __global__ __launch_bounds__(256) void k_lines_bluestein(const LineArgs a) {
             fft.template compute_rev<LAST>(v);
         }
         fft.template store<LAST>(v, j0, [&](int i, c32 val) {
-            const bool in = ok && i < a.n;
-            const c32 b = a.chirp[in ? i : 0];   // requested outside the branch
-            const c32 res = DIR < 0 ? cmul(val, b) : cmulc(val, b);
-            if (in) dl[(size_t)i * a.es] = res;
+            if (ok && i < a.n) {
+                const c32 b = a.chirp[i];
+                dl[(size_t)i * a.es] = DIR < 0 ? cmul(val, b) : cmulc(val, b);
+            }
         });
         if (P::NSTEP > 1) __syncthreads();
     }
