@@ -5,10 +5,10 @@
 // ---------------------------------------------------------------------------
 // Row pass: DFT over x of contiguous rows, B = 256/T rows per workgroup step.
 // ---------------------------------------------------------------------------
-// FW: the launch reads and writes the full width of whole batches of rows (xa = wa = 0, xb = wb = N, nrows % B == 0, checked
-// by the launcher): no predicate anywhere.  With predicates every `pred ? load : zero` sits in a branch of its own and each
-// request waits for the previous one (67 branches, one request in flight per thread, at every size).
-template <int N, int DIR, bool FW = false>
+// (A full-width variant without the predicates below -- they put every request into a branch of its own -- was measured SLOWER by the
+// wall clock: 4096 x 512^2 pair 12.45 -> 12.80 ms, 1024 x 1024^2 33.8 -> 34.15 ms; the kernel is HBM bound and 16 rows per workgroup at
+// full occupancy hide the serialisation.  The fused CG stages, which carry more arithmetic per request, did gain: k_rows_fused<..., FW>.)
+template <int N, int DIR>
 __global__ __launch_bounds__(256) void k_rows(const RowArgs a) {
     using P = Plan<N>;
     using F = Fft<P, DIR>;
@@ -33,9 +33,9 @@ __global__ __launch_bounds__(256) void k_rows(const RowArgs a) {
                                  : (size_t)r * N);
         c32 v[E];
         if (a.nt & 1)
-            fft.template load<0>(v, j0, [&](int i) { return (FW || (ok && i >= a.xa && i < a.xb)) ? __builtin_nontemporal_load(srow + i) : zero; });
+            fft.template load<0>(v, j0, [&](int i) { return (ok && i >= a.xa && i < a.xb) ? __builtin_nontemporal_load(srow + i) : zero; });
         else
-            fft.template load<0>(v, j0, [&](int i) { return (FW || (ok && i >= a.xa && i < a.xb)) ? srow[i] : zero; });
+            fft.template load<0>(v, j0, [&](int i) { return (ok && i >= a.xa && i < a.xb) ? srow[i] : zero; });
         fft.template compute<0>(v);
         if (P::NSTEP > 1) {
             fft.template store<0>(v, j0, [&](int i, c32 val) { lds[L::at(f, i)] = val; });
@@ -52,11 +52,11 @@ __global__ __launch_bounds__(256) void k_rows(const RowArgs a) {
         }
         if (a.nt & 2)
             fft.template store<LAST>(v, j0, [&](int i, c32 val) {
-                if (FW || (ok && i >= a.wa && i < a.wb)) __builtin_nontemporal_store(val, drow + i);
+                if (ok && i >= a.wa && i < a.wb) __builtin_nontemporal_store(val, drow + i);
             });
         else
             fft.template store<LAST>(v, j0, [&](int i, c32 val) {
-                if (FW || (ok && i >= a.wa && i < a.wb)) drow[i] = val;
+                if (ok && i >= a.wa && i < a.wb) drow[i] = val;
             });
         if (P::NSTEP > 1) row_sync<T>();
     }
