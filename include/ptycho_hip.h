@@ -15,7 +15,14 @@
  *     arguments; ptycho_last_error() describes the last failure of the calling
  *     thread (the reference returns void and checks nothing);
  *   - the caller's HIP stream is passed explicitly (the reference uses the
- *     legacy default stream); no per-call state is kept in the handle;
+ *     legacy default stream); no per-call operand state is kept in the handle.
+ *     Calls on ONE handle must be stream-serialised (same stream, or ordered by
+ *     events): the handle owns scratch that the kernels of a call share -- the
+ *     adjoint's intermediate, the position order, the CG work slots, the
+ *     fixed-point image of the deterministic adjoints, and the ticket + partial-sum
+ *     table through which every CG reduction adds up its workgroups in a fixed
+ *     order.  Two stage calls of one handle running concurrently on different
+ *     streams would mix their partial sums; use one handle per stream;
  *   - taps outside the object read as zero / are dropped instead of being
  *     undefined behaviour (the reference only rejects negative positions,
  *     src/cuda/kernels.cu:39).
@@ -57,7 +64,9 @@ int ptycho_create(ptycho_handle* out, size_t ptheta, size_t nz, size_t n,
 int ptycho_free(ptycho_handle h);
 /* ~ptychofft: free + release the handle itself. */
 int ptycho_destroy(ptycho_handle h);
-/* read-only size fields: which = 0 ptheta, 1 nz, 2 n, 3 nscan, 4 ndet, 5 nprb. */
+/* read-only size fields: which = 0 ptheta, 1 nz, 2 n, 3 nscan, 4 ndet, 5 nprb;
+ * 100: positions per launch pair of the adjoint (option "chunk"), 101: option "window";
+ * 200 + slot (slot < 16): 1 if CG work slot `slot` (one farplane, ptheta * nscan * ndet^2 * 8 bytes) is allocated. */
 long long ptycho_get(ptycho_handle h, int which);
 
 /* g = F Q f : probe (x) bilinear patch, 1/ndet, centred zero pad, 2-D DFT. */
@@ -182,7 +191,9 @@ int ptycho_cg_zoom(ptycho_handle h, const void* image_product, const void* best,
  *                         state[COST] <- cost (:347-353); grad <- adj (raw, not yet divided by max|probe|^2; stored, no
  *                         zero fill needed with the deterministic adjoints).   all-reduce: grad
  *                         Option "defer_finish" (single GPU): grad stays in the adjoint's fixed-point image and
- *                         ptycho_cg_obj_dir folds it in -- do not read grad between the two calls.
+ *                         ptycho_cg_obj_dir folds it in -- do not read grad between the two calls; a deterministic
+ *                         adjoint (ptycho_adj, ptycho_cg_adj_cols, ptycho_cg_prb_grad) issued in between fails with
+ *                         PTYCHO_ERR_ARG instead of adding into the pending image.
  *   ptycho_cg_obj_dir     grad /= max|probe|^2 (:356); Dai-Yuan dpsi, grad0 <- grad (:366-373); slot 1 <- column
  *                         pass of fwd(dpsi, probe); first line-search pass (:383-393).
  *                                                                    all-reduce: state[PTYCHO_ST_COSTS .. +119)
@@ -276,6 +287,8 @@ int ptycho_cg_cross_dev(ptycho_handle h, int slot1, int slot2, const double* gam
  * "compact_modes" (M = number of probe modes: compact slot layout + chunk-major position order, see above; 0 = slot pairs);
  * "defer_finish", "ls_fused_decide" (native CG stages on one GPU, see above; default 0);
  * "release_scratch" (any value: frees the adjoint's intermediate, which the fused CG stages never use; ptycho_adj re-allocates it);
+ * "release_work" (value = slot: frees that CG work slot; the next stage that writes the slot allocates it again.  The native
+ * loop with the position correction's shared gathers holds slots 0-3, without them 0-1 (+2 with a process group));
  * "trust_order" is the CALLER's: the native CG stages track the scan buffer themselves and do not touch it.
  * Experiments build only (make experiments, -DPTYCHO_EXPERIMENTS; the shipped library rejects / ignores them):
  * "fused" (ndet = 256: forward operator as ONE launch that keeps the column<->row intermediate on the CU,
@@ -291,7 +304,8 @@ int ptycho_set_option(ptycho_handle h, const char* name, long long value);
  * (index 0 k_cols<FWD>, 1 k_rows<fwd>, 2 k_rows<inv>, 3 k_cols<ADJ_OBJ>,
  * 4 k_cols<ADJ_PRB>, 5 k_cols<PLAIN>, 6 position sort, 7 / 8 / 9 fused CG row passes (statistics / projection /
  * line search), 10 unused, 11 single-launch forward (experiments build), 12 unused, 13 cross row pass,
- * 14 arg-max column pass, 15 zoomed DFT + arg-max, 16 / 17 one-launch forward / probe adjoint of ndet <= 128; n >= 18)
+ * 14 arg-max column pass, 15 zoomed DFT + arg-max, 16 / 17 one-launch forward / probe adjoint of ndet <= 128; n >= 16:
+ * arrays of 16 entries, as earlier versions of this header asked for, simply do not receive ids 16 / 17)
  * and clears the record.
  * No counterpart in the reference (it has no timing code). */
 int ptycho_profile(ptycho_handle h, int enable);

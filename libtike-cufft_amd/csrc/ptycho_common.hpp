@@ -182,6 +182,9 @@ __device__ __forceinline__ void row_sync() {
 // totals.  Hand-off = write-through (sc1) 8-byte stores, drained, then one agent-scope ticket add per workgroup; the
 // last arriver reads the rows with sc1 loads (MI355X_MICROARCH.md, "Valid forms", row 1 of the hand-off table).
 // ---------------------------------------------------------------------------------------------------------------
+// One ticket and one table per handle: the kernels that fold must be stream-serialised (include/ptycho_hip.h, "Calls on
+// ONE handle"), which every caller in this repository is.  The ticket counts modulo the grid size (atomicInc wraps it to
+// zero at gridDim.x - 1), so it needs no reset store that a later launch could miss.
 constexpr int kFoldStride = 128;   // values per workgroup row (>= 7 groups x 17 line-search costs)
 struct FoldBuf {
     unsigned long long* part;   // [rows][kFoldStride] doubles as bits; rows >= gridDim.x of every kernel that folds
@@ -200,7 +203,7 @@ __device__ __forceinline__ bool fold_across_workgroups(const FoldBuf fb, double*
         __hip_atomic_store(mine + i, (unsigned long long)__double_as_longlong(vals[i]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (tid == 0) fold_last = atomicAdd(fb.ticket, 1u) == gridDim.x - 1 ? 1 : 0;
+    if (tid == 0) fold_last = atomicInc(fb.ticket, gridDim.x - 1) == gridDim.x - 1 ? 1 : 0;   // wraps to 0 with the last arrival
     __syncthreads();
     if (!fold_last) return false;
     int nvp = 1;
@@ -222,7 +225,6 @@ __device__ __forceinline__ bool fold_across_workgroups(const FoldBuf fb, double*
         for (int gg = 1; gg < G; ++gg) t = is_max ? fmax(t, scratch[gg * nvp + tid]) : t + scratch[gg * nvp + tid];
         vals[tid] = t;
     }
-    if (tid == 0) *fb.ticket = 0u;      // ready for the next kernel on the stream
     __syncthreads();
     return true;
 }

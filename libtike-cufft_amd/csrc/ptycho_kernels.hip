@@ -451,6 +451,10 @@ int det_begin(ptycho_handle h, ColArgs& ca, const c32* gsrc, long long gcount, c
               const double* known_omax = nullptr) {
     const Geom& ge = h->ge;
     const size_t nobj = (size_t)ge.ptheta * ge.nz * ge.n, nprb = (size_t)ge.ptheta * ge.nprb * ge.nprb;
+    // option "defer_finish": a gradient that ptycho_cg_obj_grad / prb_grad left in the fixed-point image has not been
+    // folded in yet (ptycho_cg_obj_dir / prb_dir do that); another deterministic adjoint would add into the same image
+    if (h->det_pending)
+        return fail(PTYCHO_ERR_ARG, "a deferred gradient is pending in the fixed-point image: call ptycho_cg_obj_dir / ptycho_cg_prb_dir first");
     if (!h->det_acc) {
         const size_t words = 2 * (nobj > nprb ? nobj : nprb);
         HIP_TRY(hipMalloc((void**)&h->det_acc, words * sizeof(long long)));
@@ -500,6 +504,10 @@ int do_adj(ptycho_handle h, c32* f, const c32* g, const float* scan, c32* prb, i
     // object are neighbours in time, which is what the LDS overlap-add window needs
     int rc = sort_positions(h, scan, st);
     if (rc) return rc;
+    if (!h->scratch) {   // the row pass's output (up to 4 GiB), allocated by the first call that gets here
+        rc = alloc_scratch(h);
+        if (rc) return rc;
+    }
     ColArgs det{};
     if (h->deterministic) {
         if (!(h->use_window && WinCfg<N>::fits)) return fail(PTYCHO_ERR_ARG, "option deterministic needs the windowed adjoint kernels (ndet <= 512)");
@@ -772,6 +780,10 @@ int do_adj_generic(ptycho_handle h, c32* f, const c32* g, const float* scan, c32
     const size_t tile = (size_t)ge.ndet * ge.ndet;
     // object adjoint: LDS overlap-add window over runs of sorted positions (k_adjwin_generic) when the window fits
     const size_t win_bytes = (size_t)(ge.nprb + 8) * (16 + kBucketPx) * sizeof(c32);
+    if (!h->scratch) {
+        int rc0 = alloc_scratch(h);
+        if (rc0) return rc0;
+    }
     bool windowed = flg == 0 && h->use_window && win_bytes + sizeof(RunMeta) + 256 <= 160 * 1024;
     if (windowed && win_bytes > 48 * 1024 &&
         hipFuncSetAttribute((const void*)k_adjwin_generic, hipFuncAttributeMaxDynamicSharedMemorySize, (int)win_bytes) != hipSuccess) {
@@ -1039,7 +1051,9 @@ long long ptycho_get(ptycho_handle h, int which) {
         case 5: return h->ge.nprb;
         case 100: return h->chunk;
         case 101: return h->use_window;
-        default: return -1;
+        default:
+            if (which >= 200 && which < 200 + ptycho_handle_s::kSlots) return h->work[which - 200] ? 1 : 0;   // CG work slot allocated?
+            return -1;
     }
 }
 
@@ -1097,6 +1111,13 @@ int ptycho_set_option(ptycho_handle h, const char* name, long long value) {
         if (h->scratch) { HIP_TRY(hipFree(h->scratch)); h->scratch = nullptr; }
         return PTYCHO_OK;
     }
+    if (std::strcmp(name, "release_work") == 0) {   // give back one CG work slot (a farplane); the next stage that writes it allocates it again
+        if (value < 0 || value >= ptycho_handle_s::kSlots) return fail(PTYCHO_ERR_ARG, "work slot out of range");
+        HIP_TRY(hipDeviceSynchronize());
+        if (h->work[value]) { HIP_TRY(hipFree(h->work[value])); h->work[value] = nullptr; }
+        h->slot_max_ok[value] = false;
+        return PTYCHO_OK;
+    }
     if (std::strcmp(name, "defer_finish") == 0) {
         h->defer_finish = value != 0;
         h->det_pending = false;
@@ -1119,14 +1140,16 @@ int ptycho_profile(ptycho_handle h, int enable) {
 int ptycho_profile_read(ptycho_handle h, double* ms, long long* launches, int n) {
     int rc = check_handle(h);
     if (rc) return rc;
-    if (!ms || !launches || n < K_COUNT) return fail(PTYCHO_ERR_ARG, "need arrays of at least 18 entries");
+    if (!ms || !launches || n < 16) return fail(PTYCHO_ERR_ARG, "need arrays of at least 16 entries (18 for every kernel id)");
     for (int i = 0; i < n; ++i) { ms[i] = 0.0; launches[i] = 0; }
     for (auto& sp : h->spans) {
         HIP_TRY(hipEventSynchronize(sp.b));
         float t = 0.f;
         HIP_TRY(hipEventElapsedTime(&t, sp.a, sp.b));
-        ms[sp.kid] += t;
-        launches[sp.kid] += 1;
+        if (sp.kid < n) {   // callers with the 16-entry arrays of earlier headers do not see ids 16 / 17
+            ms[sp.kid] += t;
+            launches[sp.kid] += 1;
+        }
         (void)hipEventDestroy(sp.a);
         (void)hipEventDestroy(sp.b);
     }
@@ -1150,10 +1173,6 @@ int ptycho_adj(ptycho_handle h, void* f, const void* g, const void* scan, void* 
     if (!g || !f || !scan || !prb) return fail(PTYCHO_ERR_ARG, "null operand");
     if (flg != 0 && flg != 1) return fail(PTYCHO_ERR_ARG, "flg must be 0 (object) or 1 (probe)");
     h->native_order = 0;
-    if (!h->scratch) {
-        rc = alloc_scratch(h);
-        if (rc) return rc;
-    }
     hipStream_t st = (hipStream_t)stream;
     if (h->bs_m) { PTY_DISPATCH(h->bs_m, (do_adj_generic<NN>(h, (c32*)f, (const c32*)g, (const float*)scan, (c32*)prb, flg, st))); }
     PTY_DISPATCH(h->ge.ndet, (do_adj<NN>(h, (c32*)f, (const c32*)g, (const float*)scan, (c32*)prb, flg, st)));

@@ -747,13 +747,32 @@ class CGPtychoSolver(PtychoHIP):
                     self._allreduce(costs)
                 nat.check(nat.cg_ls_next(h, sp, which, p, _ptr(data), use_ab, S))
 
+        # Sharing the patch gathers keeps FOUR farplane-sized work slots on the device (0, 1 and, for the two operands of
+        # the position correction, 2 and 3) instead of two: 2 x ptheta x nscan x ndet^2 x 8 bytes more (4 GiB at configs[1],
+        # 16 GiB at a configs[3] shard).  Where that does not fit next to what is already allocated the loop runs without
+        # sharing (two more column passes per iteration: 8.33 -> 8.39 ms at 4096 x 256^2) and gives slots 2 / 3 back.
+        share_fits = self.share_ones and self.ndet <= 512 and self.ptheta == 1 and piter > 1
+        if share_fits:
+            slot_bytes = (self.ptheta * self.nscan + 8) * self.ndet * self.ndet * 8
+            need = sum(slot_bytes for s_ in (2, 3) if nat.get(h, 200 + s_) != 1)
+            if need:
+                free_b = torch.cuda.mem_get_info(dev)[0]
+                if free_b < need + (1 << 30):
+                    torch.cuda.empty_cache()
+                    free_b = torch.cuda.mem_get_info(dev)[0]
+                share_fits = free_b >= need + (1 << 30)
+        if not share_fits:
+            for s_ in (2, 3):
+                if nat.get(h, 200 + s_) == 1 and not (s_ == 2 and dist_on):   # (slot 2 serves cg_reg_prepare with a process group)
+                    nat.check(nat.set_option(h, b"release_work", s_))
+
         def iteration(first, correct):
             """One CG iteration as a fixed sequence of launches on the current stream (no host decisions)."""
             S = _stream()
             # 1) object step (ptycho.py:325-405)
             # with the position correction on, its two operands (column passes of fwd(psi, 1) and fwd(dpsi, 1)) ride
             # along with the object step's own column passes: one patch gather per position serves both probes
-            share = bool(correct) and self.share_ones and self.ndet <= 512 and self.ptheta == 1
+            share = bool(correct) and share_fits
             # with a process group the column pass of fwd(psi, 1) is better spent under the gradient all-reduce (below)
             op_psi = _ptr(ones) if (share and not dist_on) else None
             op_dpsi = _ptr(ones) if share else None
