@@ -187,44 +187,49 @@ def shard_and_stream_figures(pt, syn, dev, iters=6):
 
 
 def generic_figures(pt, syn, dev):
-    """fwd+adj pair at a detector size that is not a power of two (the reference's tests/test_fsc.py crops to such
-    sizes): 4096 positions x (112 x 112), Bluestein lines + windowed overlap-add object adjoint."""
-    R, step, ndet = 64, 8, 112
-    nz, n = syn.object_size_for(R, R, step, ndet)
-    rng = np.random.default_rng(777)
-    psi = torch.as_tensor(syn.random_object(nz, n, rng), device=dev)
-    scan = torch.as_tensor(syn.raster_scan(R, R, step, rng), device=dev)
-    prb = torch.as_tensor(syn.gaussian_probe(ndet), device=dev)
-    slv = pt.PtychoCuFFT(R * R, ndet, ndet, 1, nz, n)
-    g = torch.empty((1, R * R, ndet, ndet), dtype=torch.complex64, device=dev)
-    o = torch.empty_like(psi)
-    for _ in range(5):
-        slv.adj(slv.fwd(psi, scan, prb, out=g), scan, prb, out=o)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(10):
-        slv.adj(slv.fwd(psi, scan, prb, out=g), scan, prb, out=o)
-    torch.cuda.synchronize()
-    ms = (time.perf_counter() - t0) / 10 * 1e3
-    slv.free()
-    # the CG loop at such a size: the statement-by-statement loop (reference expressions in torch) around these operators
-    cg = pt.CGPtychoSolver(R * R, ndet, ndet, 1, nz, n)
-    cg.verbose = False
-    prs = torch.as_tensor((syn.gaussian_probe(ndet) * np.exp(2j * np.pi * rng.random((ndet, ndet)))).astype(np.complex64), device=dev)
-    data = (torch.abs(cg.fwd(psi, scan, prs)) ** 2).contiguous()
-    cg.run(data, torch.ones_like(psi), scan.clone(), prs[:, None].clone(), piter=2)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    cg.run(data, torch.ones_like(psi), scan.clone(), prs[:, None].clone(), piter=6)
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / 6
-    cg.free()
-    pair_bytes = 2.0 * (8.0 * R * R * ndet * ndet + 8.0 * nz * n + 8.0 * ndet * ndet + 8.0 * R * R)
-    return {"generic112_workload": "4096 positions x (112x112), nprb 112: detector size that is not a power of two (Bluestein path)",
-            "generic112_pair_ms": ms, "generic112_patterns_per_s": R * R / (ms * 1e-3),
-            "generic112_roofline_frac": pair_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-            "generic112_cg_it_s": 1.0 / dt,
-            "generic112_cg_note": "statement-by-statement CG loop (torch elementwise around the HIP operators), phase-screened probe, position correction on"}
+    """fwd+adj pair and CG at detector sizes that are not a power of two (the reference's tests/test_fsc.py:115-120 crops
+    to 112): 4096 positions x (112 x 112) on the mixed-radix plan 7 x 4 x 4 (one-launch tile kernels, device-resident
+    fused CG loop), and x (100 x 100) on the Bluestein lines (statement-by-statement CG loop) for comparison."""
+    out = {}
+    for ndet, key, cg_its in ((112, "generic112_", 30), (100, "bluestein100_", 6)):
+        R, step = 64, 8
+        nz, n = syn.object_size_for(R, R, step, ndet)
+        rng = np.random.default_rng(777)
+        psi = torch.as_tensor(syn.random_object(nz, n, rng), device=dev)
+        scan = torch.as_tensor(syn.raster_scan(R, R, step, rng), device=dev)
+        prb = torch.as_tensor(syn.gaussian_probe(ndet), device=dev)
+        slv = pt.PtychoCuFFT(R * R, ndet, ndet, 1, nz, n)
+        g = torch.empty((1, R * R, ndet, ndet), dtype=torch.complex64, device=dev)
+        o = torch.empty_like(psi)
+        for _ in range(5):
+            slv.adj(slv.fwd(psi, scan, prb, out=g), scan, prb, out=o)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(10):
+            slv.adj(slv.fwd(psi, scan, prb, out=g), scan, prb, out=o)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / 10 * 1e3
+        slv.free()
+        cg = pt.CGPtychoSolver(R * R, ndet, ndet, 1, nz, n)
+        cg.verbose = False
+        prs = torch.as_tensor((syn.gaussian_probe(ndet) * np.exp(2j * np.pi * rng.random((ndet, ndet)))).astype(np.complex64), device=dev)
+        data = (torch.abs(cg.fwd(psi, scan, prs)) ** 2).contiguous()
+        cg.run(data, torch.ones_like(psi), scan.clone(), prs[:, None].clone(), piter=3)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        cg.run(data, torch.ones_like(psi), scan.clone(), prs[:, None].clone(), piter=cg_its)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / cg_its
+        cg.free()
+        pair_bytes = 2.0 * (8.0 * R * R * ndet * ndet + 8.0 * nz * n + 8.0 * ndet * ndet + 8.0 * R * R)
+        out.update({key + "pair_ms": ms, key + "patterns_per_s": R * R / (ms * 1e-3),
+                    key + "roofline_frac": pair_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    key + "cg_it_s": 1.0 / dt})
+    out["generic112_workload"] = ("4096 positions x (112x112), nprb 112: mixed-radix Stockham plan 7 x 4 x 4 (sizes 48, 80, 96, 112 have one): "
+                                  "one-launch tile forward, device-resident fused CG loop, phase-screened probe, position correction on")
+    out["bluestein100_workload"] = ("4096 positions x (100x100), nprb 100: a size without a plan of its own: Bluestein lines, "
+                                    "statement-by-statement CG loop (torch elementwise around the HIP operators)")
+    return out
 
 
 def small_tile_figures(pt, syn, dev):

@@ -2,11 +2,12 @@
 //
 // Replaces the closed-source cuFFT calls of the reference
 // (/root/reference/src/cuda/ptychofft.cu:14-20,72,85): unnormalised 1-D DFTs of
-// power-of-two length N, composed into the batched 2-D transform by the kernels
-// in ptycho_kernels.hip (columns and rows are separate passes).
+// length N = 2^a 3^b 5^c 7^d (the powers of two 16 ... 2048 and 48, 80, 96, 112, 192 -- cuFFT takes such sizes natively and the
+// reference's own script crops to 112 = 2^4 7, tests/test_fsc.py:115-120), composed into the batched 2-D transform by the
+// kernels in ptycho_kernels.hip (columns and rows are separate passes).
 //
-// One FFT of length N is computed by T = N/E threads, E = 16 points per thread
-// held in registers, as 1..3 Stockham steps of radix R_i (prod R_i = N, R_i | E).
+// One FFT of length N is computed by T = N/E threads (T a power of two), E points per thread (16 for the powers of two)
+// held in registers, as 1..3 Stockham steps of radix R_i (prod R_i = N, R_i | E; an odd prime radix comes first).
 // Between steps the points are exchanged through LDS.  In step i (Ns = prod of
 // earlier radices) butterfly j in [0, N/R) reads x[j + t*N/R], t = 0..R-1,
 // multiplies by W_{Ns*R}^{(j mod Ns) t}, does an R-point in-register DFT and
@@ -65,20 +66,67 @@ constexpr int brev(int x, int bits) {
     return r;
 }
 
-// In-register R-point DFT (R = 2..32), decimation in frequency, radix 2.
-// Output X[k] is left in v[brev(k)].
+// cos / sin (2 pi j / R), j < R, for the odd prime radices
+template <int R> struct OddTab;
+template <> struct OddTab<3> {
+    static constexpr float C[3] = { 1.000000000e+00f, -5.000000000e-01f, -5.000000000e-01f };
+    static constexpr float S[3] = { 0.000000000e+00f, 8.660254038e-01f, -8.660254038e-01f };
+};
+template <> struct OddTab<5> {
+    static constexpr float C[5] = { 1.000000000e+00f, 3.090169944e-01f, -8.090169944e-01f, -8.090169944e-01f, 3.090169944e-01f };
+    static constexpr float S[5] = { 0.000000000e+00f, 9.510565163e-01f, 5.877852523e-01f, -5.877852523e-01f, -9.510565163e-01f };
+};
+template <> struct OddTab<7> {
+    static constexpr float C[7] = { 1.000000000e+00f, 6.234898019e-01f, -2.225209340e-01f, -9.009688679e-01f, -9.009688679e-01f, -2.225209340e-01f, 6.234898019e-01f };
+    static constexpr float S[7] = { 0.000000000e+00f, 7.818314825e-01f, 9.749279122e-01f, 4.338837391e-01f, -4.338837391e-01f, -9.749279122e-01f, -7.818314825e-01f };
+};
+
+constexpr bool is_pow2(int x) { return x > 0 && (x & (x - 1)) == 0; }
+// slot of output X[k] after fft_reg<R>: bit reversed for the radix-2 networks, natural for the odd primes
+constexpr int oslot(int R, int k) { return is_pow2(R) ? brev(k, ilog2(R)) : k; }
+
+// In-register R-point DFT.  R = 2..32 (power of two): decimation in frequency, radix 2; output X[k] is left in
+// v[brev(k)].  R = 3, 5, 7: X[k] = x0 + sum_n (x_n + x_{R-n}) cos(2 pi n k / R) -/+ i sum_n (x_n - x_{R-n}) sin(2 pi n k / R),
+// n = 1 .. (R-1)/2 (the pair sums / differences are shared by X[k] and X[R-k]); output X[k] in v[k].
 template <int R, int DIR>
 PTY_FN void fft_reg(c32* v) {
+    if constexpr (is_pow2(R)) {
 #pragma unroll
-    for (int s = R / 2; s >= 1; s >>= 1) {
+        for (int s = R / 2; s >= 1; s >>= 1) {
 #pragma unroll
-        for (int a = 0; a < R; ++a) {
-            if (a & s) continue;
-            const int b = a + s;
-            const int k = a & (s - 1);
-            const c32 t = v[a] - v[b];
-            v[a] = v[a] + v[b];
-            v[b] = mul_w32<DIR>(t, k * (16 / s));
+            for (int a = 0; a < R; ++a) {
+                if (a & s) continue;
+                const int b = a + s;
+                const int k = a & (s - 1);
+                const c32 t = v[a] - v[b];
+                v[a] = v[a] + v[b];
+                v[b] = mul_w32<DIR>(t, k * (16 / s));
+            }
+        }
+    } else {
+        static_assert(R == 3 || R == 5 || R == 7, "odd radices: 3, 5, 7");
+        constexpr int H = (R - 1) / 2;
+        c32 sm[H], df[H];
+        c32 x0 = v[0], tot = v[0];
+#pragma unroll
+        for (int n = 1; n <= H; ++n) {
+            sm[n - 1] = v[n] + v[R - n];
+            df[n - 1] = v[n] - v[R - n];
+            tot = tot + sm[n - 1];
+        }
+        v[0] = tot;
+#pragma unroll
+        for (int k = 1; k <= H; ++k) {
+            c32 a = x0, b = c32{0.0f, 0.0f};
+#pragma unroll
+            for (int n = 1; n <= H; ++n) {
+                a = a + sm[n - 1] * OddTab<R>::C[(n * k) % R];
+                b = b + df[n - 1] * OddTab<R>::S[(n * k) % R];
+            }
+            // forward: X[k] = a - i b, X[R-k] = a + i b; inverse: the other way round.  -i (bx + i by) = by - i bx
+            const c32 ib = c32{b.y, -b.x};
+            v[k] = DIR < 0 ? a + ib : a - ib;
+            v[R - k] = DIR < 0 ? a - ib : a + ib;
         }
     }
 }
@@ -96,6 +144,12 @@ struct PlanT {
     static constexpr int ns(int i) { return i == 0 ? 1 : (i == 1 ? R0_ : R0_ * R1_); }
 };
 template <int N> struct Plan;
+// sizes with an odd prime factor: T = 4 (8 at 192) threads per transform, the odd radix first (no twiddles before it)
+template <> struct Plan<48> : PlanT<48, 3, 4, 4, 12> {};
+template <> struct Plan<80> : PlanT<80, 5, 4, 4, 20> {};
+template <> struct Plan<96> : PlanT<96, 3, 4, 8, 24> {};
+template <> struct Plan<112> : PlanT<112, 7, 4, 4, 28> {};
+template <> struct Plan<192> : PlanT<192, 3, 8, 8, 24> {};
 template <> struct Plan<16> : PlanT<16, 16> {};
 template <> struct Plan<32> : PlanT<32, 4, 8> {};
 template <> struct Plan<64> : PlanT<64, 8, 8> {};
@@ -122,7 +176,7 @@ struct Fft {
                 const int j = j0 + b * T;
 #pragma unroll
                 for (int t = 0; t < R; ++t) {
-                    const int k = ((j % Ns) * t * (N / (Ns * R))) & (N - 1);
+                    const int k = ((j % Ns) * t * (N / (Ns * R))) % N;
                     const c32 w = table[k];
                     tw[(st - 1) * E + b * R + t] = DIR < 0 ? w : cconj(w);
                 }
@@ -141,7 +195,7 @@ struct Fft {
             const int j = j0 + b * T;
 #pragma unroll
             for (int t = 0; t < R; ++t) {
-                const int k = ((j % Ns) * t * (N / (Ns * R))) & (N - 1);
+                const int k = ((j % Ns) * t * (N / (Ns * R))) % N;
                 const c32 w = table[k];
                 tw[(ST - 1) * E + b * R + t] = DIR < 0 ? w : cconj(w);
             }
@@ -182,7 +236,7 @@ struct Fft {
                 const int j = j0 + b * T;
 #pragma unroll
                 for (int t = 1; t < R; ++t) {
-                    const c32 w = table[((j % Ns) * t * (N / (Ns * R))) & (N - 1)];
+                    const c32 w = table[((j % Ns) * t * (N / (Ns * R))) % N];
                     v[b * R + t] = cmul(v[b * R + t], DIR < 0 ? w : cconj(w));
                 }
             }
@@ -214,7 +268,7 @@ struct Fft {
             const int j = j0 + b * T;
             const int base = (j / Ns) * Ns * R + (j % Ns);
 #pragma unroll
-            for (int t = 0; t < R; ++t) dst(base + t * Ns, v[b * R + brev(t, ilog2(R))]);
+            for (int t = 0; t < R; ++t) dst(base + t * Ns, v[b * R + oslot(R, t)]);
         }
     }
 
@@ -225,7 +279,7 @@ struct Fft {
 #pragma unroll
         for (int b = 0; b < E / R; ++b)
 #pragma unroll
-            for (int t = 0; t < R; ++t) nat[b + t * (E / R)] = v[b * R + brev(t, ilog2(R))];
+            for (int t = 0; t < R; ++t) nat[b + t * (E / R)] = v[b * R + oslot(R, t)];
     }
     PTY_FN static void from_natural(const c32* nat, c32* v) {   // before compute<0>
         constexpr int R = P::radix(0);

@@ -89,7 +89,7 @@ static double check_reg() {
     for (int k = 0; k < R; ++k) {
         std::complex<double> acc = 0;
         for (int n = 0; n < R; ++n) acc += x[n] * std::polar(1.0, DIR * 2.0 * M_PI * k * n / R);
-        c32 g = v[brev(k, ilog2(R))];
+        c32 g = v[oslot(R, k)];
         err = std::fmax(err, std::abs(acc - std::complex<double>(g.x, g.y)));
     }
     std::printf("reg R=%d dir=%d err=%.3e\n", R, DIR, err);
@@ -105,6 +105,22 @@ int main() {
     worst = std::fmax(worst, check_reg<32, -1>());
     worst = std::fmax(worst, check_reg<16, 1>());
     worst = std::fmax(worst, check_reg<8, 1>());
+    worst = std::fmax(worst, check_reg<3, -1>());
+    worst = std::fmax(worst, check_reg<5, -1>());
+    worst = std::fmax(worst, check_reg<7, -1>());
+    worst = std::fmax(worst, check_reg<3, 1>());
+    worst = std::fmax(worst, check_reg<5, 1>());
+    worst = std::fmax(worst, check_reg<7, 1>());
+    worst = std::fmax(worst, check_plan<48, -1>());
+    worst = std::fmax(worst, check_plan<80, -1>());
+    worst = std::fmax(worst, check_plan<96, -1>());
+    worst = std::fmax(worst, check_plan<112, -1>());
+    worst = std::fmax(worst, check_plan<192, -1>());
+    worst = std::fmax(worst, check_plan<48, 1>());
+    worst = std::fmax(worst, check_plan<80, 1>());
+    worst = std::fmax(worst, check_plan<96, 1>());
+    worst = std::fmax(worst, check_plan<112, 1>());
+    worst = std::fmax(worst, check_plan<192, 1>());
     worst = std::fmax(worst, check_plan<16, -1>());
     worst = std::fmax(worst, check_plan<32, -1>());
     worst = std::fmax(worst, check_plan<64, -1>());

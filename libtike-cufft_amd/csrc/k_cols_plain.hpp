@@ -144,7 +144,7 @@ __global__ __launch_bounds__(ColCfg<N>::NT) void k_cols(const ColArgs a) {
                 for (int tt = 0; tt < RL; ++tt) {
                     const int iy = base + tt * NsL - ge.pad;
                     if (col_ok && iy >= 0 && iy < ge.nprb) {
-                        const c32 val = v[b * RL + brev(tt, ilog2(RL))];
+                        const c32 val = v[b * RL + oslot(RL, tt)];
                         pr[b * RL + tt] += cmulc(val, bilerp(ft, q.sy + iy, q.sx + ix, q, ge));
                     }
                 }
@@ -158,7 +158,7 @@ __global__ __launch_bounds__(ColCfg<N>::NT) void k_cols(const ColArgs a) {
                 const int base = (j / NsL) * NsL * RL + (j % NsL);
 #pragma unroll
                 for (int tt = 0; tt < RL; ++tt) {
-                    const c32 val = v[b * RL + brev(tt, ilog2(RL))];
+                    const c32 val = v[b * RL + oslot(RL, tt)];
                     const c32 w = pr[b * RL + tt];
                     lds[(base + tt * NsL) * C + c] = c32{w.x * val.x + w.y * val.y, w.x * val.y - w.y * val.x};
                 }

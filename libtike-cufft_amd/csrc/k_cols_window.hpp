@@ -23,15 +23,18 @@ struct WinCfg {
     static constexpr bool fits = (size_t)((N + 2) * (C + 2) + H * WC) * sizeof(c32) <= 160 * 1024;
 };
 
-template <int N, bool SPLIT = false>
-__global__ __launch_bounds__(ColCfg<N>::NT) void k_cols_adjwin(const ColArgs a, const int seglen) {
+// CW: columns per strip (0: ColCfg<N>::C).  Round 4 tried 8-column strips for the CG column stages of small problems (a GPU's
+// share of a strongly scaled job): twice the workgroups, half the work per position -- measured SLOWER at 256 / 512 / 1024
+// positions (0.79 / 1.37 / 2.61 against 0.77 / 1.23 / 2.32 ms per iteration, profiles/r04/narrow_strips.txt); not instantiated.
+template <int N, bool SPLIT = false, int CW = 0>
+__global__ __launch_bounds__(Plan<N>::T * (CW ? CW : ColCfg<N>::C)) void k_cols_adjwin(const ColArgs a, const int seglen) {
     // SPLIT (N = 256): the tile already went through the first radix-16 step in k_rows_split;
     // only the twiddled second step runs here, straight from global memory (no exchange).
     using P = Plan<N>;
     using F = Fft<P, +1>;
-    constexpr int E = P::E, T = P::T, C = ColCfg<N>::C, NT = ColCfg<N>::NT;
+    constexpr int E = P::E, T = P::T, C = CW ? CW : ColCfg<N>::C, NT = T * C;
     constexpr int LAST = P::NSTEP - 1;
-    constexpr int WC = WinCfg<N>::WC, H = WinCfg<N>::H;
+    constexpr int WC = C + kBucketPx, H = WinCfg<N>::H;
     // exchange buffer = T tile, stored with a zero border: element (row i, column c) lives at
     // (i + 1) * CP + (c + 1); the border is written once and never touched again, which makes
     // the four bilinear taps of the combine unconditional loads.
@@ -72,6 +75,7 @@ __global__ __launch_bounds__(ColCfg<N>::NT) void k_cols_adjwin(const ColArgs a, 
             const c32 v = win[slot];
             win[slot] = zero;
             const int X = X0 + col;
+            if ((PTY_AB & 8) && v.x != 123.456f) continue;   // A/B ablation (wrong results): price of the flush atomics
             if ((v.x != 0.0f || v.y != 0.0f) && Y < ge.nz && X >= 0 && X < ge.n) {
                 const size_t e = ((size_t)t_w * ge.nz + Y) * ge.n + X;
                 if (a.det_acc) {
@@ -109,7 +113,9 @@ __global__ __launch_bounds__(ColCfg<N>::NT) void k_cols_adjwin(const ColArgs a, 
         return st;
     };
     auto tile_of = [&](const St& st, int k) {
-        return a.src + (size_t)(a.natural_tiles ? st.p : (k - a.k_begin)) * N * N;
+        // A/B ablation bit 16 (wrong results): 128-byte row pieces that straddle two 128-byte lines, as object-space bands
+        // (a workgroup owns 16 OBJECT columns: the tile columns it needs move with every position) would read them
+        return a.src + (size_t)(a.natural_tiles ? st.p : (k - a.k_begin)) * N * N + (((PTY_AB & 16) && k + 1 < a.k_end && st.p + 1 < ge.ptheta * ge.nscan) ? ((st.p & 7) + 1) : 0);
     };
 
     __syncthreads();
@@ -134,7 +140,7 @@ __global__ __launch_bounds__(ColCfg<N>::NT) void k_cols_adjwin(const ColArgs a, 
             continue;
         }
         const Pos q = st.q;
-        if (st.t != cur_t) {
+        if (st.t != cur_t || (PTY_AB & 32)) {   // A/B bit 32: reloaded for every position (object-space bands would have to)
             const c32* prb = a.aux + (size_t)st.t * ge.nprb * ge.nprb;
 #pragma unroll
             for (int m = 0; m < E; ++m) {
@@ -243,14 +249,25 @@ __global__ __launch_bounds__(ColCfg<N>::NT) void k_cols_adjwin(const ColArgs a, 
                         int su = slot + u;
                         su = su >= H ? su - H : su;
                         wp[u] = win + su * WC + colw;
-                        t0[u] = tq[1]; t1[u] = tq[0];
+                        if (PTY_AB & 64) { t0[u] = c32{w00, w01}; t1[u] = c32{w10, (float)u}; }   // A/B ablation: no tile reads
+                        else { t0[u] = tq[1]; t1[u] = tq[0]; }
                     }
+                    if (PTY_AB & 128) {   // A/B ablation: no window read-modify-write (one store at the end of the trip keeps the sums alive)
+                        c32 accw = zero;
+#pragma unroll
+                        for (int u = 0; u < U; ++u) {
+                            accw += t0[u] * w00 + t1[u] * w01 + up0 * w10 + up1 * w11;
+                            up0 = t0[u]; up1 = t1[u];
+                        }
+                        if (accw.x == 123.456f) *wp[0] = accw;
+                    } else {
 #pragma unroll
                     for (int u = 0; u < U; ++u) wv[u] = *wp[u];
 #pragma unroll
                     for (int u = 0; u < U; ++u) {
                         *wp[u] = wv[u] + (t0[u] * w00 + t1[u] * w01 + up0 * w10 + up1 * w11);
                         up0 = t0[u]; up1 = t1[u];
+                    }
                     }
                     tp += U * CP;
                     slot += U;

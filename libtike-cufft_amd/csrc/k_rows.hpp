@@ -275,8 +275,13 @@ __device__ inline void ls_decide_dev(double* __restrict__ st, const int which, c
 // latency chains: two waves per SIMD (<= 256 registers) took the ndet = 256 line search from 2.0 to 1.3 ms.
 // (The plain row pass k_rows<512> is the opposite case: forced from 2 to 3 or 4 waves per SIMD, with the twiddles
 // in registers or re-read from LDS, it went 3.24 -> 3.41 / 3.43 ms; it keeps the compiler's 185 registers.)
+#ifndef PTY_AB
+#define PTY_AB 0
+#endif
 template <int N, int EP>
 constexpr int fused_min_waves() {
+    if ((PTY_AB & 1) && N == 512 && EP == EP_LINESEARCH_M) return 1;   // A/B: no spills at one wave per SIMD
+    if (!is_pow2(N)) return 1;   // 48 ... 192 with an odd factor: 12-28 points per thread, no register cap (no spills)
     return (N <= 512 && (EP == EP_LINESEARCH || EP == EP_LINESEARCH_M || EP == EP_PROJECT || EP == EP_CROSS)) ? 2
            : (N == 512 && (EP == EP_STATS || EP == EP_STATS_M)) ? 3 : 1;
 }

@@ -34,6 +34,9 @@ struct TileCfg {
     static constexpr int NT = TT * TPW;
     static constexpr int LS = N + 1;                          // LDS row stride (elements)
     static constexpr size_t lds_bytes = (size_t)TPW * N * LS * sizeof(c32) + N * sizeof(c32);
+    // every wave lies inside ONE j0 (its 64 lanes are consecutive columns of the same row block): ndet a multiple of 64.
+    // Then the row arithmetic of the gathers is wave-uniform (scalar unit); otherwise (16, 32 and 48, 80, 96, 112) per lane
+    static constexpr bool WAVE_J0 = NL % 64 == 0;
 };
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -155,7 +158,7 @@ __device__ __forceinline__ void tile_patch_rows(const c32* __restrict__ ft, cons
 }
 template <int N, int BATCH, class Fn>
 __device__ __forceinline__ void tile_exit_taps(const c32* __restrict__ ft, const Pos& q, const Geom& ge, int j0, int ix, bool col_ok, Fn fn) {
-    if constexpr (TileCfg<N>::NL >= 64) tile_patch_rows<Plan<N>, BATCH>(ft, q, ge, uni_i(j0), ix, col_ok, fn);
+    if constexpr (TileCfg<N>::WAVE_J0) tile_patch_rows<Plan<N>, BATCH>(ft, q, ge, uni_i(j0), ix, col_ok, fn);
     else tile_patch<Plan<N>, BATCH>(ft, q, ge, j0, ix, col_ok, fn);
 }
 
@@ -207,7 +210,7 @@ __device__ __forceinline__ void tile_exit_block(const c32* __restrict__ ft, cons
 template <int N>
 __device__ __forceinline__ Pos tile_pos(const float* __restrict__ scan, int p, const Geom& ge) {
     Pos q = decode_pos(scan, p, ge);
-    if (TileCfg<N>::TT >= 64) {
+    if (TileCfg<N>::TPW == 1) {   // one tile per workgroup: every lane decodes the same position
         q.sy = uni_i(q.sy); q.sx = uni_i(q.sx);
         q.fy = uni_f(q.fy); q.fx = uni_f(q.fx);
         q.valid = uni_i(q.valid) != 0; q.inside = uni_i(q.inside) != 0;
@@ -238,6 +241,11 @@ __global__ __launch_bounds__(TileCfg<N>::NT) void k_fwd_tile(const TileArgs a) {
         const Pos q = tile_pos<N>(a.scan, p, ge);
         const c32* ft = a.obj + (size_t)th * ge.nz * ge.n;
         c32 v[CPT][E];
+        // (plans with more than 16 points per thread -- 48 ... 112 --: an opaque copy of j0 keeps the E probe-row addresses and the
+        // 2 x E twiddle addresses of each transform inside the position loop; hoisted out of it they cost k_fwd_tile<112> 115
+        // spilled registers)
+        int jv = j0;
+        if constexpr (E > 16) asm volatile("" : "+v"(jv));
         // ---- exit waves of the thread's columns (kernels.cu:95-107): blocks of 16 consecutive rows -> tile -> DFT over y ----
         // (requesting the NEXT position's rows before this tile streams out and finishing them afterwards was measured
         // slower, twice: 0.322 against 0.217 ms at ndet = 128, 0.070 against 0.046 ms at 64 -- 68 registers of raw rows or 32 of
@@ -248,23 +256,25 @@ __global__ __launch_bounds__(TileCfg<N>::NT) void k_fwd_tile(const TileArgs a) {
             const bool col_ok = ix >= 0 && ix < ge.nprb;
             c32 ex[E];
             if (q.valid) {
-                tile_exit_block<N>(ft, a.prb + (size_t)th * ge.nprb * ge.nprb, q, ge, NL >= 64 ? uni_i(j0) : j0, ix, col_ok, cinv, ex);
+                tile_exit_block<N>(ft, a.prb + (size_t)th * ge.nprb * ge.nprb, q, ge, CF::WAVE_J0 ? uni_i(j0) : jv, ix, col_ok, cinv, ex);
             } else {
 #pragma unroll
                 for (int k = 0; k < E; ++k) ex[k] = zero;
             }
 #pragma unroll
-            for (int k = 0; k < E; ++k) tile[(E * j0 + k) * LS + l] = ex[k];
+            for (int k = 0; k < E; ++k) tile[(E * jv + k) * LS + l] = ex[k];
         }
         __syncthreads();
-        tile_dft<N, -1, false, true>(v, tile, wtab, c, j0);
+        if constexpr (E > 16) asm volatile("" : "+v"(jv));
+        tile_dft<N, -1, false, true>(v, tile, wtab, c, jv);
         if (P::NSTEP > 1) __syncthreads();   // the exchange slots have been read: the tile may take the column results
-        tile_put<N, -1, false>(v, tile, c, j0);   // [ky][x]
+        tile_put<N, -1, false>(v, tile, c, jv);   // [ky][x]
         __syncthreads();
         // ---- DFT over x of the thread's rows ---------------------------------------------------------------
-        tile_dft<N, -1, true, true>(v, tile, wtab, c, j0);
+        if constexpr (E > 16) asm volatile("" : "+v"(jv));
+        tile_dft<N, -1, true, true>(v, tile, wtab, c, jv);
         if (P::NSTEP > 1) __syncthreads();
-        tile_put<N, -1, true>(v, tile, c, j0);    // [ky][kx]
+        tile_put<N, -1, true>(v, tile, c, jv);    // [ky][kx]
         __syncthreads();
         // ---- whole rows to g, 16 bytes per lane -----------------------------------------------------------
         if (live) {
@@ -365,7 +375,7 @@ __global__ __launch_bounds__(TileCfg<N>::NT) void k_adjprb_tile(const TileArgs a
                 // (packed tiles, ndet <= 32, keep the branch: without it the per-lane row arithmetic of all 16 rows is hoisted and
                 // the kernel takes 255 registers, 0.136 against 0.093 ms at 16384 x 32^2)
                 tile_exit_taps<N, 4>(ft, q, ge, j0, ix, col_ok, [&](int m, bool ok, c32 val) {
-                    if (NL >= 64 || ok) acc[h][m] += cmulc(nat[m], val);
+                    if (CF::WAVE_J0 || ok) acc[h][m] += cmulc(nat[m], val);
                 });
             }
         }

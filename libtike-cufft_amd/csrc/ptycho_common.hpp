@@ -14,7 +14,13 @@ struct ColCfg {
     static constexpr int T = Plan<N>::T;
     static constexpr int C0 = (256 / T) > 16 ? (256 / T) : 16;
     static constexpr int C1 = C0 > N ? N : C0;
-    static constexpr int C = T * C1 > 1024 ? 1024 / T : C1;   // detector columns per strip (<= 1024 threads)
+    static constexpr int C2 = T * C1 > 1024 ? 1024 / T : C1;
+    static constexpr int divisor_below(int n, int c) { return n % c == 0 ? c : divisor_below(n, c - 1); }
+    // detector columns per strip (<= 1024 threads; strips tile the N columns).  Plans with an odd factor (four threads of 12-28
+    // points per column): 80, 96, 112 take 16-column strips, i.e. ONE wave per workgroup and four workgroups per CU -- the widest
+    // strips that divide N (56 at 112: 224 threads, 110 KiB of LDS, one workgroup per CU) gave 212 / 272 / 234 CG iterations per
+    // second at 112 / 96 / 80 against 278 / 340 / 308 (profiles/r04/mixed_radix.txt); 48 keeps its single 48-column strip (1032 against 465)
+    static constexpr int C = is_pow2(N) ? C2 : divisor_below(N, N >= 80 ? 16 : C2);
     static constexpr int NT = T * C;            // threads per workgroup
 };
 

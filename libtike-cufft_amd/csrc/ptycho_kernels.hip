@@ -204,9 +204,9 @@ int launch_cols(ptycho_handle h, ColArgs a, hipStream_t st) {
     return PTYCHO_OK;
 }
 
-template <int N, bool SPLIT = false>
+template <int N, bool SPLIT = false, int CW = 0>
 int launch_adjwin(ptycho_handle h, ColArgs a, hipStream_t st, int wg_target = 0) {
-    using CC = ColCfg<N>;
+    constexpr int NTHREADS = Plan<N>::T * (CW ? CW : ColCfg<N>::C);
     const int np = a.k_end - a.k_begin;
     if (np <= 0 || a.nstrips <= 0) return PTYCHO_OK;
     // contiguous runs of the sorted order; about 4 workgroups per CU in total
@@ -226,7 +226,7 @@ int launch_adjwin(ptycho_handle h, ColArgs a, hipStream_t st, int wg_target = 0)
 #endif
     {
         ProfSpan ps(h, K_COLS_ADJ_OBJ, st);
-        hipLaunchKernelGGL((k_cols_adjwin<N, SPLIT>), dim3((unsigned)(a.nstrips * nseg)), dim3(CC::NT), 0, st, a, seglen);
+        hipLaunchKernelGGL((k_cols_adjwin<N, SPLIT, CW>), dim3((unsigned)(a.nstrips * nseg)), dim3(NTHREADS), 0, st, a, seglen);
     }
     HIP_TRY(hipGetLastError());
     return PTYCHO_OK;
@@ -644,7 +644,7 @@ int do_cg_fwd_cols(ptycho_handle h, int slot, const c32* f, const float* scan, c
     const Geom& ge = h->ge;
     const long long total = (long long)ge.ptheta * ge.nscan;
     int strip0, nstrips;
-    strip_range<N>(ge, strip0, nstrips);
+    strip_range<N>(h->ge, strip0, nstrips);
     const bool window = h->use_window && WinCfg<N>::fits;
     int rc = PTYCHO_OK;
     if (window) {
@@ -672,7 +672,7 @@ int do_cg_adj_cols(ptycho_handle h, int slot, c32* f, const float* scan, c32* pr
     const Geom& ge = h->ge;
     const long long total = (long long)ge.ptheta * ge.nscan;
     int strip0, nstrips;
-    strip_range<N>(ge, strip0, nstrips);
+    strip_range<N>(h->ge, strip0, nstrips);
     int rc = sort_positions(h, scan, st);
     if (rc) return rc;
     ColArgs ca{};
@@ -851,8 +851,21 @@ int do_fft2_generic(ptycho_handle h, c32* dst, const c32* src, long long nbatch,
                    : launch_lines<M, +1>(h, dst, dst, nbatch, true, nullptr, st);
 }
 
+// detector sizes with their own Stockham plan (fft_core.hpp): the powers of two 16 ... 2048 and four sizes with an odd factor
+inline bool native_size(size_t n) {
+    return ((n & (n - 1)) == 0 && n >= 16 && n <= 2048) || n == 48 || n == 80 || n == 96 || n == 112;
+}
+#ifdef PTY_FEW_SIZES   // A/B builds (make ab): the two benchmarked sizes only -- a quarter of the compile time
+#define PTY_DISPATCH_POW2_CASES(CALL)                             \
+        case 256: { constexpr int NN = 256; return CALL; }       \
+        case 512: { constexpr int NN = 512; return CALL; }
 #define PTY_DISPATCH(N_, CALL)                                   \
     switch (N_) {                                                \
+        PTY_DISPATCH_POW2_CASES(CALL)                            \
+        default: return fail(PTYCHO_ERR_ARG, "A/B build: ndet 256 and 512 only"); \
+    }
+#else
+#define PTY_DISPATCH_POW2_CASES(CALL)                             \
         case 16: { constexpr int NN = 16; return CALL; }         \
         case 32: { constexpr int NN = 32; return CALL; }         \
         case 64: { constexpr int NN = 64; return CALL; }         \
@@ -860,8 +873,22 @@ int do_fft2_generic(ptycho_handle h, c32* dst, const c32* src, long long nbatch,
         case 256: { constexpr int NN = 256; return CALL; }       \
         case 512: { constexpr int NN = 512; return CALL; }       \
         case 1024: { constexpr int NN = 1024; return CALL; }     \
-        case 2048: { constexpr int NN = 2048; return CALL; }     \
-        default: return fail(PTYCHO_ERR_ARG, "this entry point needs a power-of-two detector size in [16, 2048]"); \
+        case 2048: { constexpr int NN = 2048; return CALL; }
+#define PTY_DISPATCH(N_, CALL)                                   \
+    switch (N_) {                                                \
+        PTY_DISPATCH_POW2_CASES(CALL)                            \
+        case 48: { constexpr int NN = 48; return CALL; }         \
+        case 80: { constexpr int NN = 80; return CALL; }         \
+        case 96: { constexpr int NN = 96; return CALL; }         \
+        case 112: { constexpr int NN = 112; return CALL; }       \
+        default: return fail(PTYCHO_ERR_ARG, "this entry point needs a detector size with a Stockham plan: a power of two in [16, 2048] or 48, 80, 96, 112"); \
+    }
+#endif
+// length of a Bluestein plan: always a power of two
+#define PTY_DISPATCH_POW2(N_, CALL)                              \
+    switch (N_) {                                                \
+        PTY_DISPATCH_POW2_CASES(CALL)                            \
+        default: return fail(PTYCHO_ERR_ARG, "internal: Bluestein plan length is not a power of two"); \
     }
 
 int check_handle(ptycho_handle h) {
@@ -938,7 +965,7 @@ int ptycho_create(ptycho_handle* out, size_t ptheta, size_t nz, size_t n, size_t
     *out = nullptr;
     if (ptheta == 0 || nz == 0 || n == 0 || nscan == 0 || ndet == 0 || nprb == 0)
         return fail(PTYCHO_ERR_ARG, "all sizes must be positive");
-    const bool pow2 = (ndet & (ndet - 1)) == 0 && ndet >= 16;
+    const bool pow2 = native_size(ndet);   // (name kept: "has a plan of its own"; every other size runs the Bluestein lines)
     if (ndet < 2 || ndet > 2048 || (!pow2 && ndet > 1024))
         return fail(PTYCHO_ERR_ARG, "ndet must be in [2, 1024], or a power of two up to 2048");
     if (nprb > ndet) return fail(PTYCHO_ERR_ARG, "nprb must be <= ndet");
@@ -1163,7 +1190,7 @@ int ptycho_fwd(ptycho_handle h, void* g, const void* f, const void* scan, const 
     if (!g || !f || !scan || !prb) return fail(PTYCHO_ERR_ARG, "null operand");
     hipStream_t st = (hipStream_t)stream;
     h->native_order = 0;
-    if (h->bs_m) { PTY_DISPATCH(h->bs_m, (do_fwd_generic<NN>(h, (c32*)g, (const c32*)f, (const float*)scan, (const c32*)prb, st))); }
+    if (h->bs_m) { PTY_DISPATCH_POW2(h->bs_m, (do_fwd_generic<NN>(h, (c32*)g, (const c32*)f, (const float*)scan, (const c32*)prb, st))); }
     PTY_DISPATCH(h->ge.ndet, (do_fwd<NN>(h, (c32*)g, (const c32*)f, (const float*)scan, (const c32*)prb, st)));
 }
 
@@ -1174,7 +1201,7 @@ int ptycho_adj(ptycho_handle h, void* f, const void* g, const void* scan, void* 
     if (flg != 0 && flg != 1) return fail(PTYCHO_ERR_ARG, "flg must be 0 (object) or 1 (probe)");
     h->native_order = 0;
     hipStream_t st = (hipStream_t)stream;
-    if (h->bs_m) { PTY_DISPATCH(h->bs_m, (do_adj_generic<NN>(h, (c32*)f, (const c32*)g, (const float*)scan, (c32*)prb, flg, st))); }
+    if (h->bs_m) { PTY_DISPATCH_POW2(h->bs_m, (do_adj_generic<NN>(h, (c32*)f, (const c32*)g, (const float*)scan, (c32*)prb, flg, st))); }
     PTY_DISPATCH(h->ge.ndet, (do_adj<NN>(h, (c32*)f, (const c32*)g, (const float*)scan, (c32*)prb, flg, st)));
 }
 
@@ -1309,7 +1336,7 @@ int ptycho_fft2(ptycho_handle h, void* dst, const void* src, size_t nbatch, int 
     if (dir != -1 && dir != 1) return fail(PTYCHO_ERR_ARG, "dir must be -1 (forward) or +1 (inverse)");
     if (nbatch == 0) return PTYCHO_OK;
     hipStream_t st = (hipStream_t)stream;
-    if (h->bs_m) { PTY_DISPATCH(h->bs_m, (do_fft2_generic<NN>(h, (c32*)dst, (const c32*)src, (long long)nbatch, dir, st))); }
+    if (h->bs_m) { PTY_DISPATCH_POW2(h->bs_m, (do_fft2_generic<NN>(h, (c32*)dst, (const c32*)src, (long long)nbatch, dir, st))); }
     PTY_DISPATCH(h->ge.ndet, (do_fft2<NN>(h, (c32*)dst, (const c32*)src, (long long)nbatch, dir, st)));
 }
 
@@ -1735,9 +1762,9 @@ int ptycho_cg_prb_finish(ptycho_handle h, double* state, void* prb, const void* 
 // ---- several probe modes per column pass; compact slot layout with a chunked line search ----
 namespace {
 
-template <int N, int NM>
+template <int N, int NM, int CW = 0>
 int launch_gatherwin_modes(ptycho_handle h, ColArgs a, hipStream_t st) {
-    using CC = ColCfg<N>;
+    constexpr int NTHREADS = Plan<N>::T * (CW ? CW : ColCfg<N>::C);
     const int np = a.k_end - a.k_begin;
     if (np <= 0 || a.nstrips <= 0) return PTYCHO_OK;
     int nseg = (h->n_cu * 4 + a.nstrips - 1) / a.nstrips;
@@ -1749,7 +1776,7 @@ int launch_gatherwin_modes(ptycho_handle h, ColArgs a, hipStream_t st) {
     a.nt = 0;
     {
         ProfSpan ps(h, K_COLS_FWD, st);
-        hipLaunchKernelGGL((k_cols_gatherwin<N, M_FWD, false, NM>), dim3((unsigned)(a.nstrips * nseg)), dim3(CC::NT), 0, st, a, seglen);
+        hipLaunchKernelGGL((k_cols_gatherwin<N, M_FWD, false, NM, CW>), dim3((unsigned)(a.nstrips * nseg)), dim3(NTHREADS), 0, st, a, seglen);
     }
     HIP_TRY(hipGetLastError());
     return PTYCHO_OK;
@@ -1760,14 +1787,14 @@ int do_cg_fwd_cols_modes(ptycho_handle h, int nmodes, c32* const* dst, const c32
                          int k_begin, int k_end, hipStream_t st, const double* skip) {
     const Geom& ge = h->ge;
     int strip0, nstrips;
-    strip_range<N>(ge, strip0, nstrips);
+    strip_range<N>(h->ge, strip0, nstrips);
     int rc = sort_positions(h, scan, st);
     if (rc) return rc;
     ColArgs ca{};
     ca.src = f; ca.scan = scan; ca.table = h->table; ca.ge = ge; ca.order = h->order;
     ca.k_begin = k_begin; ca.k_end = k_end; ca.strip0 = strip0; ca.nstrips = nstrips;
     ca.skip = skip;
-    static const int nm_max = exp_env("PTYCHO_HIP_NMMAX", 4);   // comparison knob
+    static const int nm_max = exp_env("PTYCHO_HIP_NMMAX", (PTY_AB & 2) ? 2 : ((PTY_AB & 4) ? 1 : 4));   // comparison knob
     int k = 0;
     while (k < nmodes) {
         const int left = nmodes - k;

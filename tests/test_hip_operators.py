@@ -67,6 +67,15 @@ CASES = [
     (64, 40, 3, 3, 9, 1),
     (128, 128, 4, 5, 11, 1),
     (128, 100, 3, 3, 11, 1),
+    # sizes with an odd prime factor and a Stockham plan of their own (radix 3 / 5 / 7 first, fft_core.hpp)
+    (48, 48, 3, 4, 7, 1),
+    (48, 30, 3, 3, 7, 2),
+    (80, 80, 3, 3, 9, 1),
+    (80, 55, 2, 3, 9, 1),
+    (96, 96, 3, 4, 9, 2),
+    (96, 70, 3, 3, 9, 1),
+    (112, 112, 3, 4, 11, 1),
+    (112, 75, 3, 3, 11, 2),
     (256, 256, 3, 4, 13, 1),
     (256, 128, 2, 3, 13, 2),
     (512, 512, 2, 2, 17, 1),
@@ -103,7 +112,8 @@ def test_fwd_adj_adjprobe_match_oracle(pt, ndet, nprb, ny, nx, step, ntheta):
             assert e[0] < REL_MAX and e[1] < REL_L2, ("adj_probe", tile, e)
 
 
-@pytest.mark.parametrize("ndet,nprb,ny,nx", [(16, 16, 151, 65), (32, 27, 67, 39), (64, 64, 41, 19), (128, 100, 17, 9)])
+@pytest.mark.parametrize("ndet,nprb,ny,nx", [(16, 16, 151, 65), (32, 27, 67, 39), (64, 64, 41, 19), (128, 100, 17, 9),
+                                               (48, 40, 50, 21), (80, 80, 24, 11), (96, 96, 20, 9), (112, 90, 19, 9)])
 def test_tile_kernels_equal_the_two_pass_kernels(pt, ndet, nprb, ny, nx):
     """ndet <= 128, more positions than one trip of the persistent workgroups holds, a count that does not fill the last
     workgroup, two angles (the probe adjoint's accumulators are flushed at the angle change), padded probes, skipped and
@@ -229,14 +239,15 @@ def test_optional_paths_give_the_same_results(pt):
         assert np.abs(again - ref[1]).max() <= 1e-5 * np.abs(ref[1]).max()
 
 
-def test_deterministic_adjoints_at_a_size_that_is_not_a_power_of_two(pt):
-    """Option deterministic on the Bluestein path (ndet 112): both adjoints equal the float-atomic ones to rounding and
-    are bitwise equal between two calls."""
+@pytest.mark.parametrize("ndet", [100, 112])
+def test_deterministic_adjoints_at_a_size_that_is_not_a_power_of_two(pt, ndet):
+    """Option deterministic on the Bluestein path (ndet 100) and on a mixed-radix plan (112 = 7 x 4 x 4): both adjoints
+    equal the float-atomic ones to rounding and are bitwise equal between two calls."""
     import torch
-    p = syn.make_problem(12, 12, 6, 112, 112, seed=8)
+    p = syn.make_problem(12, 12, 6, ndet, ndet, seed=8)
     rng = np.random.default_rng(2)
-    y = (rng.standard_normal((1, 144, 112, 112)) + 1j * rng.standard_normal((1, 144, 112, 112))).astype(np.complex64)
-    with pt.PtychoCuFFT(144, 112, 112, 1, p["nz"], p["n"]) as slv:
+    y = (rng.standard_normal((1, 144, ndet, ndet)) + 1j * rng.standard_normal((1, 144, ndet, ndet))).astype(np.complex64)
+    with pt.PtychoCuFFT(144, ndet, ndet, 1, p["nz"], p["n"]) as slv:
         psi, scan, prb, yd = dev(p["psi"]), dev(p["scan"]), dev(p["probe"]), dev(y)
         ref = [host(slv.adj(yd, scan, prb)), host(slv.adj_probe(yd, scan, psi))]
         slv.set_deterministic(True)
@@ -251,8 +262,8 @@ def test_fft2_matches_numpy(pt):
     rng = np.random.default_rng(0)
     # ndet <= 128: one launch with the tile in LDS (default) and the two-pass kernels; 1100 tiles of 64^2 are more than one
     # trip of the persistent workgroups
-    for ndet, nb, tile in [(n, 3, True) for n in (16, 32, 64, 128, 256, 512, 1024, 2048)] + \
-                          [(n, 3, False) for n in (16, 32, 64, 128)] + [(64, 1100, True), (16, 37, True)]:
+    for ndet, nb, tile in [(n, 3, True) for n in (16, 32, 48, 64, 80, 96, 112, 128, 256, 512, 1024, 2048)] + \
+                          [(n, 3, False) for n in (16, 32, 48, 64, 80, 96, 112, 128)] + [(64, 1100, True), (16, 37, True), (112, 600, True)]:
         x = (rng.standard_normal((nb, ndet, ndet)) + 1j * rng.standard_normal((nb, ndet, ndet))).astype(np.complex64)
         with pt.PtychoCuFFT(1, ndet, ndet, 1, ndet + 2, ndet + 2) as slv:
             slv.set_tile(tile)
@@ -352,7 +363,7 @@ def test_error_behaviour(pt):
 
 
 # ---- detector sizes that are not a power of two (cuFFT takes any size, ptychofft.cu:13-20) ----------------
-@pytest.mark.parametrize("ndet", [12, 30, 96, 100, 112, 200, 1000])
+@pytest.mark.parametrize("ndet", [12, 30, 48, 80, 96, 100, 112, 200, 1000])   # 48, 80, 96, 112: own plans; the others: Bluestein
 def test_fft2_any_size_matches_numpy(pt, ndet):
     rng = np.random.default_rng(ndet)
     nb = 3 if ndet < 500 else 2
@@ -366,14 +377,14 @@ def test_fft2_any_size_matches_numpy(pt, ndet):
     assert np.abs(back - wantb).max() <= 2e-6 * np.abs(wantb).max()
 
 
-@pytest.mark.parametrize("ndet,nprb,ntheta", [(112, 112, 1), (100, 64, 2), (30, 17, 1)])
+@pytest.mark.parametrize("ndet,nprb,ntheta", [(112, 112, 1), (96, 64, 2), (100, 64, 2), (30, 17, 1), (200, 140, 1)])
 def test_operators_any_detector_size_match_oracle(pt, ndet, nprb, ntheta):
     """/root/reference/tests/test_fsc.py:115-120 crops the detector and the probe from 128 to 112:
     fwd / adj / adj_probe at such sizes against the oracle, and the adjoint identity."""
     p = syn.make_problem(4, 5, 7, nprb, ndet, ntheta=ntheta, seed=ndet)
     rng = np.random.default_rng(1)
     scan = p["scan"].copy()
-    scan[0, 0] = (-0.5, 1.0) if ndet == 100 else scan[0, 0]   # -0.0 integer part: NOT skipped, negative fraction (kernels.cu:39)
+    scan[0, 0] = (-0.5, 1.0) if ndet in (96, 100) else scan[0, 0]   # -0.0 integer part: NOT skipped, negative fraction (kernels.cu:39)
     prb = (p["probe"] * np.exp(2j * np.pi * rng.random((nprb, nprb)))).astype(np.complex64)
     y = (rng.standard_normal((ntheta, p["nscan"], ndet, ndet)) + 1j * rng.standard_normal((ntheta, p["nscan"], ndet, ndet))).astype(np.complex64)
     with pt.PtychoCuFFT(p["nscan"], nprb, ndet, ntheta, p["nz"], p["n"]) as slv:
