@@ -490,13 +490,15 @@ def main():
     dom_bytes = op_bytes / dom["launches_per_step"]
     # HBM traffic per step from the committed rocprofv3 PMC passes of this same command
     # (profiles/traffic.json; a live PMC read is not possible from inside the process)
-    traffic, traffic_src = None, None
+    traffic, traffic_src, dom_own = None, None, None
     try:
         tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
         names = tj["roles"]     # bench kernel role -> rocprof kernel name of the profiled build
         if ndet == 256 and nprb == 256 and nscan == 4096 and all(names.get(k, "") in tj["kernels"] for k in kern):
-            traffic = sum(tj["kernels"][names[k]].get("fetch_bytes_per_launch", 0.0)
-                          + tj["kernels"][names[k]].get("write_bytes_per_launch", 0.0) for k in kern)
+            per = {k: tj["kernels"][names[k]].get("fetch_bytes_per_launch", 0.0)
+                      + tj["kernels"][names[k]].get("write_bytes_per_launch", 0.0) for k in kern}
+            traffic = sum(per.values())
+            dom_own = per[dominant]
             traffic_src = tj["source"]
     except Exception:
         pass
@@ -506,12 +508,20 @@ def main():
         "traffic": traffic, "traffic_unit": "HBM bytes per step (fwd+adj pair), PMC", "traffic_source": traffic_src,
         "what": "fwd+adj pair: %.4e algorithmic B per %d-position batch (16*ndet^2 B/pattern "
                 "+ object, probe, scan) / measured ms_per_step" % (pair_bytes, nscan),
+        # the kernel with the longest duration per step.  Two different questions, two keys: (1) what share of the operator's
+        # ALGORITHMIC bytes its duration alone would allow ("operator_bytes_over_this_kernel": a ceiling on the operator's own
+        # fraction, NOT a kernel efficiency -- the operator has a second kernel); (2) how fast the kernel moves the bytes it
+        # really touches ("own_traffic_*", from the PMC passes of profiles/traffic.json: for the row pass the intermediate in
+        # and the farplane out)
         "dominant_kernel": {
             "name": dominant, "avg_ms_per_launch": dom["avg_ms_per_launch"],
             "launches_per_step": dom["launches_per_step"],
-            "algorithmic_bytes_per_launch": dom_bytes,
-            "achieved_GBs": dom_bytes / (1e-3 * dom["avg_ms_per_launch"]) / 1e9,
-            "frac": dom_bytes / (1e-3 * dom["avg_ms_per_launch"]) / 1e9 / HBM_PEAK_GBS,
+            "operator_algorithmic_bytes_per_launch": dom_bytes,
+            "operator_bytes_over_this_kernel_GBs": dom_bytes / (1e-3 * dom["avg_ms_per_launch"]) / 1e9,
+            "operator_bytes_over_this_kernel_frac": dom_bytes / (1e-3 * dom["avg_ms_per_launch"]) / 1e9 / HBM_PEAK_GBS,
+            "own_traffic_bytes_per_launch": dom_own,
+            "own_traffic_GBs": (dom_own / (1e-3 * dom["avg_ms_per_launch"]) / 1e9) if dom_own else None,
+            "own_traffic_frac_of_peak": (dom_own / (1e-3 * dom["avg_ms_per_launch"]) / 1e9 / HBM_PEAK_GBS) if dom_own else None,
         },
         "kernels": kern,
         "kernel_ms_per_step": kernel_ms, "pair_ms_hip_events": pair_ms_events,

@@ -334,7 +334,7 @@ def test_cg_runs_are_bitwise_reproducible(pt):
 
 
 def test_fused_registration_right_on_its_first_launch():
-    """DESIGN.md (round 1) recorded an occupancy-capped variant of the registration row pass that was wrong on its
+    """NOTEBOOK.md (round 1) recorded an occupancy-capped variant of the registration row pass that was wrong on its
     first launch in a process and right afterwards.  That variant is gone; this pins the shipped path: in a FRESH
     process, the very first solver calls are the fused position-correction kernels (two ones-probe column passes,
     CROSS, arg-max, zoom) on never-used work slots, checked against the un-fused registration (HIP operators +
