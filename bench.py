@@ -225,7 +225,7 @@ def generic_figures(pt, syn, dev):
         out.update({key + "pair_ms": ms, key + "patterns_per_s": R * R / (ms * 1e-3),
                     key + "roofline_frac": pair_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                     key + "cg_it_s": 1.0 / dt})
-    out["generic112_workload"] = ("4096 positions x (112x112), nprb 112: mixed-radix Stockham plan 7 x 4 x 4 (sizes 48, 80, 96, 112 have one): "
+    out["generic112_workload"] = ("4096 positions x (112x112), nprb 112: mixed-radix Stockham plan 7 x 4 x 4 (sizes 48, 80, 96, 112, 192 have one): "
                                   "one-launch tile forward, device-resident fused CG loop, phase-screened probe, position correction on")
     out["bluestein100_workload"] = ("4096 positions x (100x100), nprb 100: a size without a plan of its own: Bluestein lines, "
                                     "statement-by-statement CG loop (torch elementwise around the HIP operators)")

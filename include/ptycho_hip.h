@@ -34,7 +34,7 @@
  *   prb  probe    complex64 [ptheta][nprb][nprb]
  *   scan          float32   [ptheta][nscan][2]  ([..][0] = row/y, [..][1] = column/x)
  * ndet: 2 .. 1024, or a power of two up to 2048.  Sizes with a Stockham plan of their own run the fused kernels and the
- * CG stages below: the powers of two 16 .. 2048 and 48, 80, 96, 112 (mixed radix 3 / 5 / 7 x 4 x 4|8; 112 is the crop of the
+ * CG stages below: the powers of two 16 .. 2048 and 48, 80, 96, 112, 192 (mixed radix 3 / 5 / 7 x 4|8 x 4|8; 112 is the crop of the
  * reference's tests/test_fsc.py:115-120); every other size runs a Bluestein transform on the next power-of-two plan (operators
  * and ptycho_fft2 only).  nprb <= ndet.
  */

@@ -405,7 +405,15 @@ __global__ __launch_bounds__(256, (fused_min_waves<N, EP>())) void k_rows_fused(
         if constexpr (FW) asm volatile("" : "+v"(rowm));
         c32 v[E], g1[E];
         const c32* __restrict__ first_src = (EP == EP_LINESEARCH_M || EP == EP_STATS_M) ? a.sm[0] : a.s1;
-        fft.template load<0>(v, j0, [&](int i) { if constexpr (FW) return load_masked(first_src + boff + (fNs + (unsigned)i), rowm); else return (ok && i >= a.xa && i < a.xb) ? __builtin_nontemporal_load(first_src + boff + (fN + (unsigned)i)) : zero; });
+        auto request = [&](const c32* __restrict__ src, c32* dstv) {
+            fft.template load<0>(dstv, j0, [&](int i) { if constexpr (FW) return load_masked(src + boff + (fNs + (unsigned)i), rowm); else return (ok && i >= a.xa && i < a.xb) ? __builtin_nontemporal_load(src + boff + (fN + (unsigned)i)) : zero; });
+        };
+        request(first_src, v);
+        // multi-mode line search: the 2 nmodes input rows of a batch are requested ONE TRANSFORM AHEAD (vn), so that the next
+        // row's HBM latency runs under the current row's transform (the kernel is latency bound: 1.8 TB/s at ndet = 512)
+        constexpr bool AHEAD = EP == EP_LINESEARCH_M && (PTY_AB & 256);
+        c32 vn[AHEAD ? E : 1];
+        if constexpr (AHEAD) request(a.sm[1], vn);
         fwd_row(v, g1);
         float d[E];
         auto load_data = [&]() {
@@ -541,15 +549,25 @@ __global__ __launch_bounds__(256, (fused_min_waves<N, EP>())) void k_rows_fused(
             for (int m = 0; m < E; ++m) { p1[m] = 0.0f; p2[m] = 0.0f; p3[m] = 0.0f; }
             for (int k = 0; k < a.nmodes; ++k) {
                 if (k > 0) {
-                    const c32* __restrict__ src1 = a.sm[2 * k];
-                    fft.template load<0>(v, j0, [&](int i) { if constexpr (FW) return load_masked(src1 + boff + (fNs + (unsigned)i), rowm); else return (ok && i >= a.xa && i < a.xb) ? __builtin_nontemporal_load(src1 + boff + (fN + (unsigned)i)) : zero; });
+                    if constexpr (AHEAD) {
+#pragma unroll
+                        for (int m = 0; m < E; ++m) v[m] = vn[m];
+                        request(a.sm[2 * k + 1], vn);
+                    } else {
+                        request(a.sm[2 * k], v);
+                    }
                     fwd_row(v, g1);
                 }
 #pragma unroll
                 for (int m = 0; m < E; ++m) stash[m * 256 + tid] = g1[m];   // t1 waits in LDS (private slots)
-                const c32* __restrict__ src2 = a.sm[2 * k + 1];
                 c32 g2[E];
-                fft.template load<0>(v, j0, [&](int i) { if constexpr (FW) return load_masked(src2 + boff + (fNs + (unsigned)i), rowm); else return (ok && i >= a.xa && i < a.xb) ? __builtin_nontemporal_load(src2 + boff + (fN + (unsigned)i)) : zero; });
+                if constexpr (AHEAD) {
+#pragma unroll
+                    for (int m = 0; m < E; ++m) v[m] = vn[m];
+                    if (k + 1 < a.nmodes) request(a.sm[2 * k + 2], vn);
+                } else {
+                    request(a.sm[2 * k + 1], v);
+                }
                 fwd_row(v, g2);
 #pragma unroll
                 for (int m = 0; m < E; ++m) {

@@ -851,9 +851,9 @@ int do_fft2_generic(ptycho_handle h, c32* dst, const c32* src, long long nbatch,
                    : launch_lines<M, +1>(h, dst, dst, nbatch, true, nullptr, st);
 }
 
-// detector sizes with their own Stockham plan (fft_core.hpp): the powers of two 16 ... 2048 and four sizes with an odd factor
+// detector sizes with their own Stockham plan (fft_core.hpp): the powers of two 16 ... 2048 and five sizes with an odd factor
 inline bool native_size(size_t n) {
-    return ((n & (n - 1)) == 0 && n >= 16 && n <= 2048) || n == 48 || n == 80 || n == 96 || n == 112;
+    return ((n & (n - 1)) == 0 && n >= 16 && n <= 2048) || n == 48 || n == 80 || n == 96 || n == 112 || n == 192;
 }
 #ifdef PTY_FEW_SIZES   // A/B builds (make ab): the two benchmarked sizes only -- a quarter of the compile time
 #define PTY_DISPATCH_POW2_CASES(CALL)                             \
@@ -881,7 +881,8 @@ inline bool native_size(size_t n) {
         case 80: { constexpr int NN = 80; return CALL; }         \
         case 96: { constexpr int NN = 96; return CALL; }         \
         case 112: { constexpr int NN = 112; return CALL; }       \
-        default: return fail(PTYCHO_ERR_ARG, "this entry point needs a detector size with a Stockham plan: a power of two in [16, 2048] or 48, 80, 96, 112"); \
+        case 192: { constexpr int NN = 192; return CALL; }       \
+        default: return fail(PTYCHO_ERR_ARG, "this entry point needs a detector size with a Stockham plan: a power of two in [16, 2048] or 48, 80, 96, 112, 192"); \
     }
 #endif
 // length of a Bluestein plan: always a power of two
@@ -958,7 +959,7 @@ int ptycho_debug_stamps(ptycho_handle h, unsigned long long* out24) {
     return PTYCHO_OK;
 }
 #endif
-const char* ptycho_version(void) { return "ptychohip 0.3 (gfx950)"; }
+const char* ptycho_version(void) { return "ptychohip 0.4 (gfx950)"; }
 
 int ptycho_create(ptycho_handle* out, size_t ptheta, size_t nz, size_t n, size_t nscan, size_t ndet, size_t nprb) {
     if (!out) return fail(PTYCHO_ERR_ARG, "out is null");

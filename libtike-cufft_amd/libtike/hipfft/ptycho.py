@@ -1086,9 +1086,9 @@ class CGPtychoSolver(PtychoHIP):
         assert probe.ndim == 4, "probe needs 4 dimensions, not %d" % probe.ndim
         nmodes = probe.shape[1]
         # the fused CG stages run on the detector sizes that have a Stockham plan of their own (csrc/fft_core.hpp): powers
-        # of two and 48, 80, 96, 112 (112 = the reference's own crop, tests/test_fsc.py:115-120); any other size: Bluestein
+        # of two and 48, 80, 96, 112, 192 (112 = the reference's own crop, tests/test_fsc.py:115-120); any other size: Bluestein
         # operators + the statement-by-statement loop below
-        pow2 = (self.ndet >= 16 and (self.ndet & (self.ndet - 1)) == 0) or self.ndet in (48, 80, 96, 112)
+        pow2 = (self.ndet >= 16 and (self.ndet & (self.ndet - 1)) == 0) or self.ndet in (48, 80, 96, 112, 192)
         # several modes: the compact slot layout runs its line search over position ranges, which needs the windowed
         # column pass (ndet <= 512); larger detectors take the statement-by-statement loop
         if self.fused and model == "gaussian" and pow2 and nmodes <= 8 and (nmodes == 1 or self.ndet <= 512):

@@ -235,10 +235,10 @@ def test_zoom_kernel_matches_torch_contraction(ndet):
         assert np.abs(got.cpu().numpy() - true).max() < 0.02
 
 
-@pytest.mark.parametrize("ndet", [112, 96, 100])
+@pytest.mark.parametrize("ndet", [112, 96, 192, 100])
 def test_cg_at_a_cropped_detector_size(pt, ndet):
-    """ndet = nprb = 112 (tests/test_fsc.py:115-120) and 96: the device-resident fused loop on the mixed-radix plans
-    (7 x 4 x 4, 3 x 4 x 8); 100: the statement-by-statement loop on the Bluestein operators.  All track the oracle."""
+    """ndet = nprb = 112 (tests/test_fsc.py:115-120), 96 and 192: the device-resident fused loop on the mixed-radix plans
+    (7 x 4 x 4, 3 x 4 x 8, 3 x 8 x 8); 100: the statement-by-statement loop on the Bluestein operators.  All track the oracle."""
     p = syn.make_problem(4, 4, 9, ndet, ndet, seed=21)
     rng = np.random.default_rng(9)
     probe = (p["probe"][:, None] * np.exp(2j * np.pi * rng.random((ndet, ndet)))).astype(np.complex64)

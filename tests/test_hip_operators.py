@@ -76,6 +76,8 @@ CASES = [
     (96, 70, 3, 3, 9, 1),
     (112, 112, 3, 4, 11, 1),
     (112, 75, 3, 3, 11, 2),
+    (192, 192, 2, 3, 13, 1),
+    (192, 130, 2, 2, 13, 2),
     (256, 256, 3, 4, 13, 1),
     (256, 128, 2, 3, 13, 2),
     (512, 512, 2, 2, 17, 1),
@@ -262,7 +264,7 @@ def test_fft2_matches_numpy(pt):
     rng = np.random.default_rng(0)
     # ndet <= 128: one launch with the tile in LDS (default) and the two-pass kernels; 1100 tiles of 64^2 are more than one
     # trip of the persistent workgroups
-    for ndet, nb, tile in [(n, 3, True) for n in (16, 32, 48, 64, 80, 96, 112, 128, 256, 512, 1024, 2048)] + \
+    for ndet, nb, tile in [(n, 3, True) for n in (16, 32, 48, 64, 80, 96, 112, 128, 192, 256, 512, 1024, 2048)] + \
                           [(n, 3, False) for n in (16, 32, 48, 64, 80, 96, 112, 128)] + [(64, 1100, True), (16, 37, True), (112, 600, True)]:
         x = (rng.standard_normal((nb, ndet, ndet)) + 1j * rng.standard_normal((nb, ndet, ndet))).astype(np.complex64)
         with pt.PtychoCuFFT(1, ndet, ndet, 1, ndet + 2, ndet + 2) as slv:
@@ -363,7 +365,7 @@ def test_error_behaviour(pt):
 
 
 # ---- detector sizes that are not a power of two (cuFFT takes any size, ptychofft.cu:13-20) ----------------
-@pytest.mark.parametrize("ndet", [12, 30, 48, 80, 96, 100, 112, 200, 1000])   # 48, 80, 96, 112: own plans; the others: Bluestein
+@pytest.mark.parametrize("ndet", [12, 30, 48, 80, 96, 100, 112, 192, 200, 1000])   # 48, 80, 96, 112, 192: own plans; the others: Bluestein
 def test_fft2_any_size_matches_numpy(pt, ndet):
     rng = np.random.default_rng(ndet)
     nb = 3 if ndet < 500 else 2
