@@ -409,11 +409,9 @@ __global__ __launch_bounds__(256, (fused_min_waves<N, EP>())) void k_rows_fused(
             fft.template load<0>(dstv, j0, [&](int i) { if constexpr (FW) return load_masked(src + boff + (fNs + (unsigned)i), rowm); else return (ok && i >= a.xa && i < a.xb) ? __builtin_nontemporal_load(src + boff + (fN + (unsigned)i)) : zero; });
         };
         request(first_src, v);
-        // multi-mode line search: the 2 nmodes input rows of a batch are requested ONE TRANSFORM AHEAD (vn), so that the next
-        // row's HBM latency runs under the current row's transform (the kernel is latency bound: 1.8 TB/s at ndet = 512)
-        constexpr bool AHEAD = EP == EP_LINESEARCH_M && (PTY_AB & 256);
-        c32 vn[AHEAD ? E : 1];
-        if constexpr (AHEAD) request(a.sm[1], vn);
+        // (Round 4 tried requesting the 2 nmodes input rows of the multi-mode line search ONE TRANSFORM AHEAD -- the kernel is
+        // latency bound, 1.8 TB/s at ndet = 512 --: 16 more live registers at the 256 cap turned 25 spilled registers into 581 and the
+        // configs[2] iteration from 126 into 441 ms; profiles/r04/cfg3_experiments.txt.)
         fwd_row(v, g1);
         float d[E];
         auto load_data = [&]() {
@@ -549,25 +547,13 @@ __global__ __launch_bounds__(256, (fused_min_waves<N, EP>())) void k_rows_fused(
             for (int m = 0; m < E; ++m) { p1[m] = 0.0f; p2[m] = 0.0f; p3[m] = 0.0f; }
             for (int k = 0; k < a.nmodes; ++k) {
                 if (k > 0) {
-                    if constexpr (AHEAD) {
-#pragma unroll
-                        for (int m = 0; m < E; ++m) v[m] = vn[m];
-                        request(a.sm[2 * k + 1], vn);
-                    } else {
-                        request(a.sm[2 * k], v);
-                    }
+                    request(a.sm[2 * k], v);
                     fwd_row(v, g1);
                 }
 #pragma unroll
                 for (int m = 0; m < E; ++m) stash[m * 256 + tid] = g1[m];   // t1 waits in LDS (private slots)
                 c32 g2[E];
-                if constexpr (AHEAD) {
-#pragma unroll
-                    for (int m = 0; m < E; ++m) v[m] = vn[m];
-                    if (k + 1 < a.nmodes) request(a.sm[2 * k + 2], vn);
-                } else {
-                    request(a.sm[2 * k + 1], v);
-                }
+                request(a.sm[2 * k + 1], v);
                 fwd_row(v, g2);
 #pragma unroll
                 for (int m = 0; m < E; ++m) {

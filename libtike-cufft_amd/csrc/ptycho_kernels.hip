@@ -1763,6 +1763,8 @@ int ptycho_cg_prb_finish(ptycho_handle h, double* state, void* prb, const void* 
 // ---- several probe modes per column pass; compact slot layout with a chunked line search ----
 namespace {
 
+// (CW: round 4 tried the two-probe pass of the CG iteration on 32-column strips in one resident round of workgroups -- 512 threads,
+// 140 KiB of LDS, one workgroup per CU --: 8.35 against 8.26 ms per iteration, profiles/r04/cg_experiments.txt; 16 columns stay)
 template <int N, int NM, int CW = 0>
 int launch_gatherwin_modes(ptycho_handle h, ColArgs a, hipStream_t st) {
     constexpr int NTHREADS = Plan<N>::T * (CW ? CW : ColCfg<N>::C);

@@ -155,6 +155,15 @@ class PtychoHIP:
         """Free the adjoint's intermediate (up to 4 GiB; ``adj`` allocates it again when needed): the fused CG loops never use it."""
         nat.check(nat.set_option(self._h, b"release_scratch", 1))
 
+    def release_work(self, slot):
+        """Free one farplane-sized CG work slot (the next stage that writes it allocates it again).  The native loop holds
+        slots 0-3 when the position correction shares the object step's patch gathers, 0-1 (+2 with a process group) without."""
+        nat.check(nat.set_option(self._h, b"release_work", int(slot)))
+
+    def work_slots_allocated(self):
+        """Indices of the CG work slots that currently hold device memory (``ptheta * nscan * ndet^2 * 8`` bytes each)."""
+        return [s for s in range(16) if nat.get(self._h, 200 + s) == 1]
+
     def set_fused(self, tiles=2):
         """ndet = 256: forward operator as one launch (``k_fwd_fused256``), ``tiles`` = 0 (off), 1 or 2."""
         nat.check(nat.set_option(self._h, b"fused", int(tiles)))

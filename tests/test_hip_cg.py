@@ -371,3 +371,42 @@ print("ok")
 ''' % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))),)
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "ok" in out.stdout, out.stdout + out.stderr
+
+
+def test_work_slots_follow_the_shared_gathers(pt):
+    """The native loop with the position correction's shared patch gathers holds FOUR farplane-sized work slots (0-3);
+    without sharing two, and the two extra ones are given back (the footprint doubled silently).  The result
+    does not depend on it, and a released slot is allocated again on demand."""
+    import torch
+    p, probe, ora, data = setup(1)
+    D = lambda x: torch.as_tensor(np.ascontiguousarray(x), device="cuda")
+    res = {}
+    with pt.CGPtychoSolver(p["nscan"], 32, 32, 1, p["nz"], p["n"]) as slv:
+        slv.verbose = False
+        for share in (True, False, True):
+            slv.share_ones = share
+            out = slv.run(D(data), torch.ones_like(D(p["psi"])), D(p["scan"]).clone(), D(probe).clone(), piter=4)
+            slots = slv.work_slots_allocated()
+            assert slots == ([0, 1, 2, 3] if share else [0, 1]), (share, slots)
+            res.setdefault(share, []).append(out["psi"].cpu().numpy())
+        slv.release_work(3)
+        assert slv.work_slots_allocated() == [0, 1, 2]
+        again = slv.run(D(data), torch.ones_like(D(p["psi"])), D(p["scan"]).clone(), D(probe).clone(), piter=4)["psi"].cpu().numpy()
+    assert np.array_equal(res[True][0], res[True][1]) and np.array_equal(res[True][0], again)
+    assert np.abs(res[True][0] - res[False][0]).max() <= 1e-5 * np.abs(res[True][0]).max()
+
+
+def test_profile_read_accepts_the_16_entry_arrays_of_earlier_headers(pt):
+    import ctypes
+    import torch
+    from libtike.hipfft import _native as nat
+    p, probe, ora, data = setup(1)
+    D = lambda x: torch.as_tensor(np.ascontiguousarray(x), device="cuda")
+    with pt.PtychoCuFFT(p["nscan"], 32, 32, 1, p["nz"], p["n"]) as slv:
+        slv.profile(True)
+        slv.fwd(D(p["psi"]), D(p["scan"]), D(probe[:, 0]))
+        ms, cnt = (ctypes.c_double * 16)(), (ctypes.c_longlong * 16)()
+        nat.check(nat.profile_read(slv._h, ms, cnt, 16))          # ids 16 / 17 (the tile kernels of ndet <= 128) are dropped
+        assert sum(cnt) == 0 or all(c >= 0 for c in cnt)
+        with pytest.raises(nat.PtychoHipError):
+            nat.check(nat.profile_read(slv._h, ms, cnt, 15))
