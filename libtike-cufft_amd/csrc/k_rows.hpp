@@ -409,9 +409,10 @@ __global__ __launch_bounds__(256, (fused_min_waves<N, EP>())) void k_rows_fused(
             fft.template load<0>(dstv, j0, [&](int i) { if constexpr (FW) return load_masked(src + boff + (fNs + (unsigned)i), rowm); else return (ok && i >= a.xa && i < a.xb) ? __builtin_nontemporal_load(src + boff + (fN + (unsigned)i)) : zero; });
         };
         request(first_src, v);
-        // (Round 4 tried requesting the 2 nmodes input rows of the multi-mode line search ONE TRANSFORM AHEAD -- the kernel is
-        // latency bound, 1.8 TB/s at ndet = 512 --: 16 more live registers at the 256 cap turned 25 spilled registers into 581 and the
-        // configs[2] iteration from 126 into 441 ms; profiles/r04/cfg3_experiments.txt.)
+        // (Round 4 tried requesting the 2 nmodes input rows of the multi-mode line search one transform AHEAD, ping-pong between two
+        // register sets: 124.8 -> 125.6-126.2 ms per configs[2] iteration -- the kernel is not waiting on its loads (SQ counters: VALU
+        // active 47 % of the SIMD cycles, issue stalls 24 %, waits 30 %); a first form that copied the prefetched row and kept the
+        // masked loads exploded to 581-1116 spilled registers and 441 ms.  profiles/r04/cfg3_experiments.txt.)
         fwd_row(v, g1);
         float d[E];
         auto load_data = [&]() {
