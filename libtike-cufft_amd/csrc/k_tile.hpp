@@ -457,3 +457,50 @@ __global__ __launch_bounds__(TileCfg<N>::NT) void k_rows_tile(const c32* src, c3
         __syncthreads();
     }
 }
+
+// Row pass of the object adjoint for the plans with four threads per row and a tile near the LDS limit (80, 96, 112): NR = 16
+// rows per workgroup trip = ONE wave per workgroup (barriers are free), 15 KiB of LDS, eight and more workgroups per CU -- the
+// whole-tile k_rows_tile holds 101 KiB at 112, i.e. one workgroup of seven waves per CU whose load / transform / store phases
+// do not overlap.  Same 16-byte-per-lane whole-row accesses.
+template <int N, int DIR, int NR = 16>
+__global__ __launch_bounds__(NR * Plan<N>::T) void k_rows_slab(const c32* __restrict__ src, c32* __restrict__ dst,
+                                                              const int* __restrict__ tile_index, const int ntiles,
+                                                              const c32* __restrict__ table) {
+    using P = Plan<N>;
+    constexpr int E = P::E, T = P::T, LS = TileCfg<N>::LS, NTH = NR * T, SPT = N / NR;
+    static_assert(N % NR == 0 && TileCfg<N>::CPT == 1, "slabs tile the rows of a tile");
+    __shared__ c32 slab[NR * LS];
+    __shared__ c32 wtab[N];
+    const int tid = threadIdx.x;
+    const int c = tid % NR, j0 = tid / NR;
+    for (int i = tid; i < N; i += NTH) wtab[i] = table[i];
+    __syncthreads();
+    const long long nitems = (long long)ntiles * SPT;
+    for (long long item = blockIdx.x; item < nitems; item += gridDim.x) {
+        const int j = (int)(item / SPT), sb = (int)(item % SPT);
+        const f32x4* in = reinterpret_cast<const f32x4*>(src + (size_t)(tile_index ? tile_index[j] : j) * N * N + (size_t)sb * NR * N);
+#pragma unroll 4
+        for (int u = tid; u < NR * N / 2; u += NTH) {
+            const int row = u / (N / 2), cu = (u % (N / 2)) * 2;
+            const f32x4 val = __builtin_nontemporal_load(in + u);
+            slab[row * LS + cu] = c32{val.x, val.y};
+            slab[row * LS + cu + 1] = c32{val.z, val.w};
+        }
+        __syncthreads();
+        c32 v[1][E];
+        int jv = j0;
+        asm volatile("" : "+v"(jv));   // keeps the twiddle addresses inside the loop (k_fwd_tile)
+        tile_dft<N, DIR, true, true>(v, slab, wtab, c, jv);
+        if (P::NSTEP > 1) __syncthreads();
+        tile_put<N, DIR, true>(v, slab, c, jv);
+        __syncthreads();
+        f32x4* out = reinterpret_cast<f32x4*>(dst + (size_t)j * N * N + (size_t)sb * NR * N);
+#pragma unroll 4
+        for (int u = tid; u < NR * N / 2; u += NTH) {
+            const int row = u / (N / 2), cu = (u % (N / 2)) * 2;
+            const c32 lo = slab[row * LS + cu], hi = slab[row * LS + cu + 1];
+            out[u] = f32x4{lo.x, lo.y, hi.x, hi.y};   // read again by the column pass: a plain store
+        }
+        __syncthreads();
+    }
+}

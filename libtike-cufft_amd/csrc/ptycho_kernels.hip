@@ -529,8 +529,15 @@ int do_adj(ptycho_handle h, c32* f, const c32* g, const float* scan, c32* prb, i
             tiled = h->use_tile && ((size_t)g % 16) == 0;
             if (tiled) {
                 ProfSpan ps(h, K_ROWS_INV, st);
-                hipLaunchKernelGGL((k_rows_tile<N, +1>), dim3(tile_grid<N>(h, k1 - k0)), dim3(TileCfg<N>::NT), 0, st, g, h->scratch,
-                                   (const int*)(h->order + k0), (int)(k1 - k0), (const c32*)h->table);
+                if constexpr (!is_pow2(N) && N >= 80) {   // 16-row slabs, one wave per workgroup (k_rows_slab)
+                    const long long items = (k1 - k0) * (N / 16);
+                    const long long cap = (long long)h->n_cu * 10;
+                    hipLaunchKernelGGL((k_rows_slab<N, +1>), dim3((unsigned)(items < cap ? items : cap)), dim3(16 * Plan<N>::T), 0, st, g, h->scratch,
+                                       (const int*)(h->order + k0), (int)(k1 - k0), (const c32*)h->table);
+                } else {
+                    hipLaunchKernelGGL((k_rows_tile<N, +1>), dim3(tile_grid<N>(h, k1 - k0)), dim3(TileCfg<N>::NT), 0, st, g, h->scratch,
+                                       (const int*)(h->order + k0), (int)(k1 - k0), (const c32*)h->table);
+                }
                 HIP_TRY(hipGetLastError());
             }
         }
