@@ -20,6 +20,8 @@ struct ColCfg {
     // points per column): 80, 96, 112 take 16-column strips, i.e. ONE wave per workgroup and four workgroups per CU -- the widest
     // strips that divide N (56 at 112: 224 threads, 110 KiB of LDS, one workgroup per CU) gave 212 / 272 / 234 CG iterations per
     // second at 112 / 96 / 80 against 278 / 340 / 308 (profiles/r04/mixed_radix.txt); 48 keeps its single 48-column strip (1032 against 465)
+    // (one-wave workgroups for the small powers of two as well -- 16 columns at 64, 8 at 128 -- measured no different at 64 and
+    // 40 % slower at 128 (64-byte row pieces): profiles/r04/narrow_strips.txt)
     static constexpr int C = is_pow2(N) ? C2 : divisor_below(N, N >= 80 ? 16 : C2);
     static constexpr int NT = T * C;            // threads per workgroup
 };

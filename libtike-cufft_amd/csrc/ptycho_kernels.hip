@@ -862,14 +862,16 @@ int do_fft2_generic(ptycho_handle h, c32* dst, const c32* src, long long nbatch,
 inline bool native_size(size_t n) {
     return ((n & (n - 1)) == 0 && n >= 16 && n <= 2048) || n == 48 || n == 80 || n == 96 || n == 112 || n == 192;
 }
-#ifdef PTY_FEW_SIZES   // A/B builds (make ab): the two benchmarked sizes only -- a quarter of the compile time
+#ifdef PTY_FEW_SIZES   // A/B builds (make ab): the benchmarked sizes only -- a third of the compile time
 #define PTY_DISPATCH_POW2_CASES(CALL)                             \
+        case 64: { constexpr int NN = 64; return CALL; }         \
+        case 128: { constexpr int NN = 128; return CALL; }       \
         case 256: { constexpr int NN = 256; return CALL; }       \
         case 512: { constexpr int NN = 512; return CALL; }
 #define PTY_DISPATCH(N_, CALL)                                   \
     switch (N_) {                                                \
         PTY_DISPATCH_POW2_CASES(CALL)                            \
-        default: return fail(PTYCHO_ERR_ARG, "A/B build: ndet 256 and 512 only"); \
+        default: return fail(PTYCHO_ERR_ARG, "A/B build: ndet 64, 128, 256 and 512 only"); \
     }
 #else
 #define PTY_DISPATCH_POW2_CASES(CALL)                             \
