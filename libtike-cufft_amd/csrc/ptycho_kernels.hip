@@ -212,7 +212,7 @@ int launch_adjwin(ptycho_handle h, ColArgs a, hipStream_t st, int wg_target = 0)
     // contiguous runs of the sorted order; about 4 workgroups per CU in total
     // ndet 256: two rounds of resident workgroups (one round of runs of 128: within 1 %, six or eight rounds: +4 %);
     // ndet 128: ONE round (two workgroups per CU, runs of 32 positions): 0.234 -> 0.197 ms at 4096 x 128^2; 64 and 32: no gain / worse
-    if (wg_target <= 0) wg_target = h->n_cu * (N == 128 ? 2 : 4);
+    if (wg_target <= 0) wg_target = h->n_cu * (N == 128 ? 2 : 4);   // (512: runs of 128 instead of 64 positions: 1.728 -> 1.709 ms, profiles/r04/stamps.txt)
     int nseg = (wg_target + a.nstrips - 1) / a.nstrips;
     if (nseg < 1) nseg = 1;
     int seglen = (np + nseg - 1) / nseg;
