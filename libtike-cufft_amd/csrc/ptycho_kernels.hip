@@ -636,6 +636,10 @@ int ensure_work(ptycho_handle h, int slot) {   // called by every stage that is 
 // deterministic option: the PROJECT stage leaves max |dst slot| on the device for the adjoint column pass that follows
 int project_maxword(ptycho_handle h, int dst_slot, RowFusedArgs& a, hipStream_t st) {
     if (!h->deterministic) return PTYCHO_OK;
+    // option "defer_finish": the pending gradient's fixed-point scale reads the max word of the slot its adjoint consumed; a
+    // projection issued before ptycho_cg_obj_dir / prb_dir folded the gradient in would overwrite that word
+    if (h->det_pending)
+        return fail(PTYCHO_ERR_ARG, "a deferred gradient is pending in the fixed-point image: call ptycho_cg_obj_dir / ptycho_cg_prb_dir first");
     if (!h->slot_maxw) {
         HIP_TRY(hipMalloc((void**)&h->slot_maxw, ptycho_handle_s::kSlots * sizeof(double)));
         HIP_TRY(hipMemset(h->slot_maxw, 0, ptycho_handle_s::kSlots * sizeof(double)));

@@ -410,3 +410,35 @@ def test_profile_read_accepts_the_16_entry_arrays_of_earlier_headers(pt):
         assert sum(cnt) == 0 or all(c >= 0 for c in cnt)
         with pytest.raises(nat.PtychoHipError):
             nat.check(nat.profile_read(slv._h, ms, cnt, 15))
+
+
+def test_pending_deferred_gradient_is_guarded(pt):
+    """Option defer_finish leaves the object gradient in the adjoint's fixed-point image until ptycho_cg_obj_dir folds it in.
+    A deterministic adjoint or a projection issued in that window used to corrupt both results silently; they
+    now fail with PTYCHO_ERR_ARG, and work again once the gradient has been folded in."""
+    import torch
+    from libtike.hipfft import _native as nat
+    from libtike.hipfft.ptycho import _ptr, _stream
+    p, probe, ora, data = setup(1)
+    D = lambda x: torch.as_tensor(np.ascontiguousarray(x), device="cuda")
+    with pt.CGPtychoSolver(p["nscan"], 32, 32, 1, p["nz"], p["n"]) as slv:
+        h = slv._h
+        nat.check(nat.set_option(h, b"deterministic", 1))
+        nat.check(nat.set_option(h, b"defer_finish", 1))
+        st = torch.zeros(nat.ST_WORDS, dtype=torch.float64, device="cuda")
+        st[nat.ST_HINT:nat.ST_HINT + 2] = 14.0
+        psi, scan, prb, dat = torch.ones_like(D(p["psi"])), D(p["scan"]), D(probe[:, 0]).contiguous(), D(data)
+        grad, grad0, dpsi = torch.empty_like(psi), torch.zeros_like(psi), torch.zeros_like(psi)
+        S = _stream()
+        nat.check(nat.cg_obj_begin(h, _ptr(st), _ptr(psi), _ptr(scan), _ptr(prb), _ptr(dat), S))
+        nat.check(nat.cg_obj_grad(h, _ptr(st), _ptr(scan), _ptr(prb), _ptr(dat), _ptr(grad), S))
+        g = torch.zeros((1, p["nscan"], 32, 32), dtype=torch.complex64, device="cuda")
+        out, cost = torch.zeros_like(psi), torch.zeros(1, dtype=torch.float64, device="cuda")
+        assert nat.adj(h, _ptr(out), _ptr(g), _ptr(scan), _ptr(prb), 0, S) != 0 and b"pending" in nat.last_error()
+        assert nat.cg_project(h, 0, 1, _ptr(dat), None, _ptr(cost), S) != 0 and b"pending" in nat.last_error()
+        nat.check(nat.cg_obj_dir(h, _ptr(st), 1, _ptr(scan), _ptr(prb), _ptr(dat), _ptr(grad), _ptr(grad0), _ptr(dpsi), S))
+        nat.check(nat.adj(h, _ptr(out), _ptr(g), _ptr(scan), _ptr(prb), 0, S))      # folded in: allowed again
+        torch.cuda.synchronize()
+        assert torch.isfinite(torch.view_as_real(dpsi)).all() and float(dpsi.abs().max()) > 0
+        nat.check(nat.set_option(h, b"defer_finish", 0))
+        nat.check(nat.set_option(h, b"deterministic", 0))
