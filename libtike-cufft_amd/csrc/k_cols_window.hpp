@@ -661,8 +661,11 @@ __global__ __launch_bounds__(Plan<N>::T * (CW ? CW : ColCfg<N>::C)) void k_cols_
                 if (km + 1 < NM) probe_strip(prnext, km + 1, st.t);   // in flight during this mode's exchange steps
             }
             if (P::NSTEP > 1) {
+                if (MODE == M_FWD) { STAMP(2) }      // un-split forward: probe product + step 0 (+ next probe strip requested)
                 fft.template store<0>(v, j0, [&](int i, c32 val) { lds[i * C + c] = val; });
+                if (MODE == M_FWD) { STAMP(3) }      // exchange store
                 __syncthreads();
+                if (MODE == M_FWD) { STAMP(4) }      // barrier A
                 if (MODE == M_FWD && km == 0) nx = prepare_issue(k + 1, ke);   // window of k is no longer read
                 fft.template load<1>(v, j0, [&](int i) { return lds[i * C + c]; });
                 if (P::NSTEP > 2) {
@@ -680,13 +683,16 @@ __global__ __launch_bounds__(Plan<N>::T * (CW ? CW : ColCfg<N>::C)) void k_cols_
                 nx = prepare_issue(k + 1, ke);
             }
             if (MODE == M_FWD) {
+                STAMP(5)      // window request + exchange load + twiddles + last step
                 c32* tile_out = (NM == 1 ? a.dst : a.dstm[km]) + (size_t)st.p * N * N;
                 if (a.nt & 4)
                     fft.template store<LAST>(v, j0, [&](int i, c32 val) { __builtin_nontemporal_store(val, tile_out + (size_t)i * N + x); });
                 else
                     fft.template store<LAST>(v, j0, [&](int i, c32 val) { tile_out[(size_t)i * N + x] = val; });
+                STAMP(6)      // store issue
                 if (km == NM - 1) prepare_commit();
                 __syncthreads();   // exchange buffer / new window rows visible to everyone
+                STAMP(7)      // window commit + barrier B
             }
         }
         if (MODE != M_FWD) {
@@ -709,7 +715,7 @@ __global__ __launch_bounds__(Plan<N>::T * (CW ? CW : ColCfg<N>::C)) void k_cols_
         st = nx;
     }
     if (MODE == M_ADJ_PRB && cur_t >= 0) flush_probe(cur_t);
-    if (MODE == M_FWD && SPLIT) { STAMP_FLUSH(a.stamps) }
+    if (MODE == M_FWD) { STAMP_FLUSH(a.stamps) }
 }
 
 // ---------------------------------------------------------------------------

@@ -1790,6 +1790,9 @@ int launch_gatherwin_modes(ptycho_handle h, ColArgs a, hipStream_t st) {
     if (seglen > kRunMax) seglen = kRunMax;
     nseg = (np + seglen - 1) / seglen;
     a.nt = 0;
+#ifdef PTY_STAMPS
+    a.stamps = h->stamps;
+#endif
     {
         ProfSpan ps(h, K_COLS_FWD, st);
         hipLaunchKernelGGL((k_cols_gatherwin<N, M_FWD, false, NM, CW>), dim3((unsigned)(a.nstrips * nseg)), dim3(NTHREADS), 0, st, a, seglen);

@@ -24,7 +24,7 @@ assert dbg(slv._h, buf) == 0          # allocates + clears
 iters = 20
 slv.run(data, torch.ones_like(psi), scan.clone(), prb[:, None].clone(), piter=iters); torch.cuda.synchronize()
 assert dbg(slv._h, buf) == 0
-names = {0: ["loop head", "gather (LDS taps + weights)", "probe product + transform", "store issue", "barrier A", "window update", "barrier B", "-", "-", "-", "-", "-"],
+names = {0: ["loop head (+ probe strip of mode 0)", "gather (LDS taps + weights)", "probe product + step 0 (+ next strip requested)", "exchange store", "barrier A", "window request + exchange load + twiddles + last step", "store issue", "window commit + barrier B", "-", "-", "-", "-"],
          1: ["loop head / probe strip", "wait for tile loads", "transform + probe product", "barrier (prev. combine done)", "window bookkeeping + flush", "barrier (T complete)", "combine", "final flush", "T store", "prefetch issue", "-", "-"]}
 for role, title in ((0, "forward column passes of the CG iteration (k_cols_gatherwin<256,FWD,unsplit,NM=2>)"), (1, "k_cols_adjwin<256,unsplit>")):
     v = np.array([buf[12 * role + i] for i in range(12)], dtype=np.float64)
